@@ -1,0 +1,170 @@
+/*
+ * neuralcx.h -- C ABI of libneuralcx_hip.so: the NeuralCX hot path on MI355X (gfx950).
+ *
+ * Drop-in boundary for gabegrand/VQA-Counterexamples.  Every entry point names the reference
+ * code it replaces (paths relative to the reference root).  The reference is pure Python on
+ * PyTorch, so "what its FFI would bind" is the body of vqa.models.cx.NeuralModel.forward and the
+ * loss / optimiser calls of the training loop in counterexamples.py; the ctypes binding a
+ * maintainer adds is shown in INTEGRATION.md and shipped in
+ * vqa-counterexamples_amd/neuralcx/_lib.py.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers + sizes + a HIP stream (hipStream_t passed as void*); no
+ *     torch types, no exceptions, no allocation inside, no global state.  The caller owns every
+ *     buffer (PyTorch's caching allocator in the shipped binding) and must keep them alive until
+ *     the enqueued work has completed.
+ *   - all floating point data is fp32, contiguous row-major; indices are int32.
+ *   - weights use torch's nn.Linear layout [out, in]; linear_1.weight keeps the reference's
+ *     concat column order (vqa/models/cx.py:309-320) so checkpoints are interchangeable.
+ *   - return value: NCX_OK (0), a negative NCX_E_* for invalid arguments (nothing was enqueued),
+ *     or a positive hipError_t passed through.
+ *   - everything is enqueued on `stream`; nothing synchronises the host.
+ *   - results are deterministic run to run (no floating point atomics anywhere).
+ */
+#ifndef NEURALCX_H
+#define NEURALCX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NCX_OK            0
+#define NCX_E_NULL       -1   /* required pointer is NULL */
+#define NCX_E_DIMS       -2   /* a dimension is out of the supported range */
+#define NCX_E_WORKSPACE  -3   /* workspace too small / misaligned */
+#define NCX_E_FLAGS      -4   /* inconsistent flags / lesion inputs */
+
+/* model_spec switches of the reference (vqa/models/cx.py:265-307), 1 = feature present */
+#define NCX_F_V_MULT   (1u << 0)   /* v_orig * v_other segment (cx.py:295-298), else zeros          */
+#define NCX_F_V_DIST   (1u << 1)   /* pairwise_distance column (cx.py:299-302), else zero           */
+#define NCX_F_V_RANK   (1u << 2)   /* one-hot candidate rank (cx.py:303-305), else inputs->v_rank   */
+#define NCX_F_A_EMB    (1u << 3)   /* answer embeddings (cx.py:279-282), else noise blocks          */
+#define NCX_F_ALL      (NCX_F_V_MULT | NCX_F_V_DIST | NCX_F_V_RANK | NCX_F_A_EMB)
+/* (v_emb / q_emb / z_emb lesions replace INPUTS by uniform noise: the host does that before the call) */
+
+typedef struct ncx_dims {
+    int32_t B;        /* triplets in this (local) batch                                             */
+    int32_t K;        /* candidates per triplet, knn_size (24 in the reference; <= 64 supported)    */
+    int32_t dv;       /* dim_v  image feature width (2048)                                          */
+    int32_t dq;       /* dim_q  question embedding width (2400)                                     */
+    int32_t dz;       /* dim_mm multimodal fusion width (360)                                       */
+    int32_t da;       /* dim_a  answer embedding width (2400, cx.py:235)                            */
+    int32_t A;        /* ans_size, rows of answer_embedding (2000)                                  */
+    int32_t H;        /* dim_h                                                                      */
+    int32_t L;        /* n_layers, 1..3                                                             */
+    int32_t n_img;    /* rows of the image feature table                                            */
+    uint32_t flags;   /* NCX_F_*                                                                    */
+    int32_t training; /* 1: apply dropout (cx.py:322-326), 0: eval                                  */
+    float   drop_p;   /* nn.Dropout p (cx.py:259)                                                   */
+    float   loss_scale; /* multiplies dscores/loss: 1/B_global (counterexamples.py:334); 0 => 1/B   */
+    uint64_t seed;    /* per-step dropout seed (counter-based generator, see oracle/ncx_oracle.py)  */
+} ncx_dims;
+
+/* Inputs of NeuralModel.forward after vqa_forward (cx.py:261-285); all DEVICE pointers.
+ * The reference gathers image_features[B,K+1,dv] on the host (counterexamples.py:540-541); here the
+ * gather is folded into the kernels: `feats` is the resident table and img_idx the rows.  A caller
+ * holding an already gathered [B,K+1,dv] block passes it as feats with img_idx = 0..B*(K+1)-1. */
+typedef struct ncx_inputs {
+    const float*   feats;        /* [n_img, dv]                                                    */
+    const int32_t* img_idx;      /* [B, K+1]  column 0 = original image, 1..K = the K candidates   */
+    const float*   q_emb;        /* [B, dq]                                                        */
+    const float*   z_orig;       /* [B, dz]                                                        */
+    const float*   z_knns;       /* [B, K, dz]                                                     */
+    const float*   a_knns;       /* NCX_F_A_EMB: [B, K, A] answer LOGITS; else [B, K, da] noise    */
+    const int32_t* answer_aids;  /* [B]   (NCX_F_A_EMB)                                            */
+    const float*   a_emb_gt;     /* [B, da] noise block, only without NCX_F_A_EMB                  */
+    const float*   v_rank;       /* [B, K, K] noise block, only without NCX_F_V_RANK               */
+    const float*   keep_mask;    /* optional explicit dropout keep masks [L][B*K][H] (0/1 floats);
+                                    NULL => counter-based generator keyed by dims->seed            */
+} ncx_inputs;
+
+/* Trainable tensors, state_dict names of the reference (cx.py:240-257). */
+typedef struct ncx_params {
+    const float* answer_embedding;  /* [A, da]                                   */
+    const float* w1;  const float* b1;   /* linear_1.weight [H, Din], .bias [H]  */
+    const float* w2;  const float* b2;   /* linear_2 [H,H],[H]   (L >= 2)        */
+    const float* w3;  const float* b3;   /* linear_3 [H,H],[H]   (L >= 3)        */
+    const float* w_out; const float* b_out; /* out.weight [1,H], out.bias [1]    */
+} ncx_params;
+
+typedef struct ncx_grads {          /* same shapes; OVERWRITTEN (not accumulated) by ncx_backward */
+    float* answer_embedding;
+    float* w1;  float* b1;
+    float* w2;  float* b2;
+    float* w3;  float* b3;
+    float* w_out; float* b_out;
+} ncx_grads;
+
+/* Din = 3*dv + 2*da + 2*dz + dq + K + 1   (cx.py:245-251) */
+int64_t ncx_input_size(const ncx_dims* d);
+
+/* Bytes of scratch + saved activations ncx_forward/ncx_backward need for `d` (256-byte aligned base
+ * required).  The same buffer must be passed to the ncx_backward that follows an ncx_forward. */
+size_t ncx_workspace_bytes(const ncx_dims* d);
+
+/* Replaces NeuralModel.forward (vqa/models/cx.py:261-333) from the answer-embedding lookups down:
+ * K3/K4 softmax(a_knns) x answer_embedding and embedding(answer_aids) (cx.py:280-282), the per
+ * candidate feature synthesis (cx.py:295-307), the concat (cx.py:309-320, never materialised),
+ * linear_1..3 + ReLU + Dropout (cx.py:322-326) and `out` (cx.py:327).  scores: [B, K]. */
+int ncx_forward(const ncx_dims* d, const ncx_inputs* in, const ncx_params* p,
+                void* workspace, size_t workspace_bytes, float* scores, void* stream);
+
+/* Replaces nn.CrossEntropyLoss(size_average=False)(scores, comp_idxs) / len(batch)
+ * (counterexamples.py:310,334) and recallAtK (counterexamples.py:501-506) in one pass.
+ *   loss_rows[B]  per-triplet CE * scale          (nullable)
+ *   loss[1]       sum of loss_rows                (nullable)
+ *   dscores[B,K]  (softmax - onehot) * scale      (nullable)   == d loss / d scores
+ *   rank[B]       #{k: s_k > s_gt} + #{k < gt: s_k == s_gt}    (nullable)
+ *   hits[2]       OVERWRITTEN with #{rank < 1}, #{rank < 5}    (nullable)
+ * scale = 1/B when scale <= 0.   K <= 64. */
+int ncx_loss_rank(const float* scores, const int32_t* gt, int32_t B, int32_t K, float scale,
+                  float* loss_rows, float* loss, float* dscores, int32_t* rank, int32_t* hits,
+                  void* stream);
+
+/* Replaces loss.backward() (counterexamples.py:338) for the tensors of ncx_params: given
+ * dscores[B,K] = d loss / d scores, writes every gradient.  vqa_model is frozen in the reference
+ * (cx.py:73-80), so no input gradients are produced. */
+int ncx_backward(const ncx_dims* d, const ncx_inputs* in, const ncx_params* p,
+                 void* workspace, size_t workspace_bytes, const float* dscores,
+                 const ncx_grads* g, void* stream);
+
+/* Replaces torch.optim.Adam(...).step() (counterexamples.py:275-276,339) on a flat fp32 buffer:
+ * defaults betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad.  `step` is the 1-based step
+ * count; grad_scale multiplies g first (1/world_size after a sum all-reduce). */
+int ncx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                  float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale,
+                  void* stream);
+
+/* ---- diagnostics (bench.py / tests only; the only process-global state, off by default) --------------
+ * GEMM ids: 0 Gt = W1[:,a_other].E^T, 1 Sh (shared segments), 2 MAIN (candidate segments, the dominant
+ * forward kernel), 3 hidden layer l>=2 forward, 4 dW1 candidate columns (+dGt; the dominant backward
+ * kernel), 5 dW1 shared columns, 6 dE, 7 dW1[:,a_other], 8 dA_gt, 9 dW_l (l>=2), 10 dX_l (l>=2).
+ * ncx_profile_begin arms HIP-event timing (on the launch stream) of every launch of ONE gemm id, including
+ * its split-K reduce; ncx_profile_end synchronises those events, writes up to `cap` durations in ms and
+ * returns how many, then disarms.  Not thread safe; do not arm during graph capture. */
+#define NCX_GEMM_GT 0
+#define NCX_GEMM_SH 1
+#define NCX_GEMM_MAIN 2
+#define NCX_GEMM_FWD_L 3
+#define NCX_GEMM_DW1C 4
+#define NCX_GEMM_DW1S 5
+#define NCX_GEMM_DE 6
+#define NCX_GEMM_DW1AK 7
+#define NCX_GEMM_DAGT 8
+#define NCX_GEMM_DWL 9
+#define NCX_GEMM_DXL 10
+int ncx_profile_begin(int32_t gemm_id, int32_t max_launches);
+int ncx_profile_end(float* ms, int32_t cap);
+/* out6 = {form (0 NT,1 TN,2 NN), M, N, 32-deep k-steps, tile cfg (0 64x64, 1 128x128, 2 96x128), ksplit} */
+int ncx_plan_query(const ncx_dims* d, int32_t gemm_id, int32_t* out6);
+
+/* Library build id ("neuralcx-hip gfx950 <date>"). */
+const char* ncx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEURALCX_H */

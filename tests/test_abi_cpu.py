@@ -1,0 +1,53 @@
+"""CPU: the C-ABI library loads and exports every symbol include/neuralcx.h declares (no compute)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "neuralcx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ncx_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    from neuralcx import _lib
+    names = _declared()
+    assert set(names) == set(_lib.EXPORTS), (names, _lib.EXPORTS)
+    assert os.path.exists(_lib.LIB_PATH), "build the library first: python -c 'import __graft_entry__ as g; g.build()'"
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), n
+
+
+def test_host_only_entry_points():
+    from neuralcx import _lib
+    from neuralcx._lib import NcxDims
+    assert "gfx950" in _lib.version()
+    d = NcxDims(B=512, K=24, dv=2048, dq=2400, dz=360, da=2400, A=2000, H=256, L=1, n_img=82783, flags=15)
+    assert _lib.lib().ncx_input_size(ctypes.byref(d)) == 14089          # cx.py:245-251
+    nbytes = _lib.lib().ncx_workspace_bytes(ctypes.byref(d))
+    assert 16 << 20 < nbytes < 1 << 30
+    bad = NcxDims(B=0, K=24, dv=1, dq=1, dz=1, da=1, A=1, H=1, L=1, n_img=1)
+    assert _lib.lib().ncx_workspace_bytes(ctypes.byref(bad)) == 0
+    # argument validation happens before any launch: NULL pointers are rejected without a GPU
+    assert _lib.lib().ncx_loss_rank(None, None, 4, 24, 0.0, None, None, None, None, None, None) == -1
+    assert _lib.lib().ncx_adam_step(None, None, None, None, 4, 1e-4, 0.9, 0.999, 1e-8, 1, 1.0, None) == -1
+
+
+def test_struct_layout_matches_header():
+    from neuralcx._lib import NcxDims, NcxInputs, NcxParams, NcxGrads
+    assert ctypes.sizeof(NcxDims) == 64
+    assert ctypes.sizeof(NcxInputs) == 80 and ctypes.sizeof(NcxParams) == 72 == ctypes.sizeof(NcxGrads)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from neuralcx import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libneuralcx_hip.so")
+    with pytest.raises(_lib.NcxError):
+        _lib.lib()

@@ -1,0 +1,227 @@
+"""GPU: the HIP path (through the C ABI) against the golden vectors of the reference and the CPU oracle.
+
+Tolerances (BASELINE.json north_star / SURVEY 8c): logits <= 1e-4 abs (fp32), loss <= 1e-5,
+gradients <= 1e-4 of the tensor's max |grad|, Recall@1/@5 vectors exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ncx_oracle as orc
+from helpers import GOLDEN, GRAD_FLOOR, check_grads_against_golden, golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+FIELD = {"answer_embedding.weight": "answer_embedding", "linear_1.weight": "w1", "linear_1.bias": "b1",
+         "linear_2.weight": "w2", "linear_2.bias": "b2", "linear_3.weight": "w3", "linear_3.bias": "b3",
+         "out.weight": "w_out", "out.bias": "b_out"}
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def to_dev_params(params):
+    return {FIELD[k]: v.to(dev()).contiguous() for k, v in params.items()}
+
+
+def to_dev_batch(batch, spec=None, keep_mask=None, extra=None):
+    from neuralcx.ops import Batch
+    extra = extra or {}
+    g = lambda k: batch[k].to(dev())
+    return Batch.from_dense(g("image_features"), g("q_emb"), g("z_orig"), g("z_knns"), g("a_knns"),
+                            g("answer_aids"), keep_mask=None if keep_mask is None else keep_mask.to(dev()),
+                            **{k: v.to(dev()) for k, v in extra.items()})
+
+
+def run_hip(d, spec, params, batch, training=False, drop_p=0.0, keep_mask=None, seed=0, extra=None):
+    from neuralcx import ops
+    b = to_dev_batch(batch, spec, keep_mask, extra)
+    p = to_dev_params(params)
+    dims = ops.make_dims(b, H=d.H, L=d.L, da=d.da, A=d.A, flags=ops.flags_from_spec(spec), training=training,
+                         drop_p=drop_p, seed=seed)
+    ws = ops.alloc_workspace(dims, dev())
+    scores = ops.forward(dims, b, p, ws)
+    gt = batch["gt"].to(dev()).to(torch.int32)
+    lr = ops.ranking_loss(scores, gt)
+    grads = {k: torch.full_like(v, float("nan")) for k, v in p.items()}
+    ops.backward(dims, b, p, ws, lr["dscores"], grads)
+    torch.cuda.synchronize()
+    inv = {v: k for k, v in FIELD.items()}
+    return (scores.cpu(), lr, {inv[k]: v.cpu().numpy() for k, v in grads.items()})
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_forward_loss_recall_backward(name):
+    g, d, spec, params, batch = load_golden(name)
+    scores, lr, grads = run_hip(d, spec, params, batch)
+    assert np.abs(scores.numpy() - g["scores"]).max() <= 1e-4
+    assert abs(float(lr["loss"].cpu()) - float(g["loss"])) <= 1e-5
+    rank = lr["rank"].cpu().numpy()
+    for k in (1, 5):
+        assert ((rank < k).astype(np.int32) == g["recall%d" % k]).all()
+    hits = lr["hits"].cpu().numpy()
+    assert hits[0] == g["recall1"].sum() and hits[1] == g["recall5"].sum()
+    for n, v in grads.items():
+        assert np.isfinite(v).all(), n
+    check_grads_against_golden(g, grads, rel=1e-4)
+
+
+def random_case(seed, B, d, scale=0.45):
+    rng = np.random.default_rng(seed)
+    t = lambda a: torch.from_numpy(a.astype(np.float32))
+    batch = dict(image_features=t(np.abs(rng.standard_normal((B, d.K + 1, d.dv))) * scale),
+                 q_emb=t(rng.standard_normal((B, d.dq)) * 0.3), z_orig=t(rng.standard_normal((B, d.dz))),
+                 z_knns=t(rng.standard_normal((B, d.K, d.dz))), a_knns=t(rng.standard_normal((B, d.K, d.A)) * 2),
+                 answer_aids=torch.from_numpy(rng.integers(0, d.A, size=B)), gt=torch.from_numpy(rng.integers(0, d.K, size=B)))
+    return batch
+
+
+def compare_with_oracle(d, spec, params, batch, training=False, drop_p=0.0, masks=None, seed=0, extra=None, use_rng=False):
+    keep = None if masks is None or use_rng else torch.stack(masks)
+    scores, lr, grads = run_hip(d, spec, params, batch, training=training, drop_p=drop_p, keep_mask=keep, seed=seed, extra=extra)
+    ob = dict(batch)
+    if extra:
+        ob.update(extra)
+    s_ref, l_ref, g_ref = orc.loss_and_grads(params, d, ob, spec=spec, drop_p=drop_p, keep_masks=masks)
+    assert np.abs(scores.numpy() - s_ref.numpy()).max() <= 1e-4
+    assert abs(float(lr["loss"].cpu()) - float(l_ref)) <= 1e-5
+    sr, gtn = s_ref.numpy(), batch["gt"].numpy()
+    gap = np.abs(sr - sr[np.arange(len(gtn)), gtn][:, None]); gap[np.arange(len(gtn)), gtn] = np.inf
+    safe = gap.min(1) > 2e-4                                  # rows without a near-tie around the ground truth
+    assert (lr["rank"].cpu().numpy()[safe] == orc.rank_of_gt(sr, gtn)[safe]).all()
+    for k, ref in g_ref.items():
+        ref = ref.numpy()
+        tol = 1e-4 * max(np.abs(ref).max(), GRAD_FLOOR)
+        err = np.abs(grads[k].reshape(ref.shape) - ref).max()
+        assert err <= tol, (k, err, tol)
+    return scores, lr, grads
+
+
+@pytest.mark.parametrize("B,K,H,L", [(1, 24, 16, 1), (7, 24, 20, 2), (13, 24, 48, 3), (5, 48, 32, 1), (33, 24, 96, 2)])
+def test_ragged_shapes_vs_oracle(B, K, H, L):
+    """Odd batch sizes / widths (nothing a multiple of the 16/32/64 tile sizes), and K = 48 (config 5)."""
+    d = orc.Dims(K=K, dv=70, dq=50, dz=18, A=45, H=H, L=L)
+    params = orc.init_params(d, seed=11 + B, gain=3.0)
+    batch = random_case(100 + B, B, d)
+    batch["answer_aids"][0] = batch["answer_aids"][B - 1]
+    compare_with_oracle(d, None, params, batch)
+
+
+def test_train_mode_explicit_masks_and_generator():
+    d = orc.Dims(dv=64, dq=48, dz=16, A=20, H=32, L=3)
+    params = orc.init_params(d, seed=5, gain=3.0)
+    batch = random_case(77, 9, d)
+    seed = 0x1234567890ABCDEF
+    masks = [orc.dropout_keep_mask(seed, l, 9 * d.K, d.H, 0.25) for l in (1, 2, 3)]
+    # (a) explicit masks handed to both sides
+    compare_with_oracle(d, None, params, batch, training=True, drop_p=0.25, masks=masks)
+    # (b) the kernel's own counter-based generator must reproduce the oracle's restatement of it
+    compare_with_oracle(d, None, params, batch, training=True, drop_p=0.25, masks=masks, seed=seed, use_rng=True)
+
+
+@pytest.mark.parametrize("spec", [dict(v_mult=False), dict(v_dist=False), dict(v_rank=False), dict(a_emb=False),
+                                  dict(v_mult=False, v_dist=False, v_rank=False, a_emb=False)])
+def test_lesion_flags_vs_oracle(spec):
+    d = orc.Dims(dv=64, dq=48, dz=16, A=20, H=32, L=2)
+    B = 6
+    params = orc.init_params(d, seed=8, gain=3.0)
+    batch = random_case(55, B, d)
+    extra = {}
+    torch.manual_seed(3)
+    if not spec.get("v_rank", True):
+        extra["v_rank"] = torch.rand(B, d.K, d.K)
+    if not spec.get("a_emb", True):
+        batch["a_knns"] = torch.rand(B, d.K, d.da)        # cx.py:285 noise block
+        extra["a_emb_gt"] = torch.rand(B, d.da)            # cx.py:284
+    full = dict(orc.DEFAULT_SPEC, **spec)
+    compare_with_oracle(d, full, params, batch, extra=extra)
+
+
+def test_full_dims_property_checks():
+    """BASELINE size (B=512, K=24, full widths, H=256): size-independent properties instead of the oracle.
+    (1) row permutation equivariance of scores; (2) shifting all K logits of a row by a constant (out.bias)
+    leaves loss/rank/dscores unchanged; (3) dscores rows sum to 0; (4) loss == mean of per-row losses."""
+    from neuralcx import ops
+    d = orc.Dims()
+    B = 512
+    torch.manual_seed(0)
+    rng = np.random.default_rng(0)
+    n_img = 4096
+    feats = (torch.randn(n_img, d.dv).abs() * 0.45).to(dev())
+    idx = torch.from_numpy(rng.integers(0, n_img, size=(B, d.K + 1)).astype(np.int32)).to(dev())
+    mk = lambda *s: torch.randn(*s, device=dev())
+    b = ops.Batch(feats, idx, mk(B, d.dq) * 0.3, mk(B, d.dz), mk(B, d.K, d.dz), mk(B, d.K, d.A) * 2,
+                  torch.from_numpy(rng.integers(0, d.A, size=B).astype(np.int32)).to(dev()))
+    p = to_dev_params(orc.init_params(d, seed=42))
+    dims = ops.make_dims(b, H=d.H, L=d.L, da=d.da, A=d.A)
+    ws = ops.alloc_workspace(dims, dev())
+    s1 = ops.forward(dims, b, p, ws).clone()
+    perm = torch.randperm(B, device=dev())
+    b2 = ops.Batch(feats, idx[perm].contiguous(), b.q_emb[perm].contiguous(), b.z_orig[perm].contiguous(),
+                   b.z_knns[perm].contiguous(), b.a_knns[perm].contiguous(), b.answer_aids[perm].contiguous())
+    s2 = ops.forward(dims, b2, p, ws)
+    assert torch.equal(s1[perm], s2)                       # same tiles, same order of operations per row
+    gt = torch.from_numpy(rng.integers(0, d.K, size=B).astype(np.int32)).to(dev())
+    r1 = ops.ranking_loss(s1, gt)
+    r2 = ops.ranking_loss(s1 + 3.25, gt)
+    assert torch.equal(r1["rank"], r2["rank"])
+    assert float((r1["loss"] - r2["loss"]).abs()) < 1e-5
+    assert float(r1["dscores"].sum(1).abs().max()) < 1e-6
+    assert abs(float(r1["loss"]) - float(r1["loss_rows"].sum())) < 1e-5
+    assert int(r1["hits"][1]) == int((r1["rank"] < 5).sum()) and int(r1["hits"][0]) == int((r1["rank"] < 1).sum())
+    # determinism: a second identical forward is bit-identical
+    assert torch.equal(ops.forward(dims, b, p, ws), s1)
+
+
+def test_loss_rank_kernel_known_answers():
+    from neuralcx import ops
+    g = dict(np.load(GOLDEN + "/g4_recall_loss.npz"))
+    for pre in ("dist", "rand"):
+        s = torch.from_numpy(g[pre + "_scores"]).to(dev())
+        gt = torch.from_numpy(g[pre + "_gt"].astype(np.int32)).to(dev())
+        r = ops.ranking_loss(s, gt)
+        rank = r["rank"].cpu().numpy()
+        for k in (1, 5):
+            assert ((rank < k).astype(np.int32) == g["%s_recall%d" % (pre, k)]).all()
+        if pre == "rand":
+            assert abs(float(r["loss"]) - float(g["rand_loss"])) < 1e-5
+            assert np.abs(r["dscores"].cpu().numpy() - g["rand_dscores"]).max() < 1e-7
+    # ties: all-equal scores -> rank == gt index (deterministic tie rule), never an undefined top-k order
+    s = torch.zeros(8, 24, device=dev())
+    gt = torch.arange(8, dtype=torch.int32, device=dev())
+    assert (ops.ranking_loss(s, gt)["rank"].cpu().numpy() == np.arange(8)).all()
+
+
+def test_fused_adam_vs_oracle_and_torch():
+    from neuralcx import ops
+    torch.manual_seed(1)
+    n = 100003
+    p0 = torch.randn(n); st = orc.AdamState(); cur = {"p": p0.clone()}
+    tp = p0.clone().requires_grad_(True); opt = torch.optim.Adam([tp], lr=1e-3)
+    P = p0.clone().to(dev()); M = torch.zeros(n, device=dev()); V = torch.zeros(n, device=dev())
+    for step in range(1, 6):
+        g = torch.randn(n) * (0.01 * step)
+        cur = orc.adam_update(cur, {"p": g}, st, lr=1e-3)
+        tp.grad = g.clone(); opt.step()
+        ops.adam_step(P, g.to(dev()), M, V, step, lr=1e-3)
+        assert torch.allclose(P.cpu(), cur["p"], rtol=2e-6, atol=1e-7)
+        assert torch.allclose(P.cpu(), tp.detach(), rtol=2e-6, atol=1e-7)
+
+
+def test_one_train_step_matches_golden_adam():
+    """G5: forward + loss + backward + Adam on the HIP path == the reference's optimizer.step()."""
+    from neuralcx import ops
+    g, d, spec, params, batch = load_golden("g1_small_L1")
+    _, lr, grads = run_hip(d, spec, params, batch)
+    for k, p0 in params.items():
+        if k == "out.bias":      # zero gradient in maths: Adam turns its round-off noise into +-lr, on every platform differently
+            continue
+        P = p0.clone().to(dev()).view(-1)
+        G = torch.from_numpy(grads[k]).to(dev()).view(-1)
+        M = torch.zeros_like(P); V = torch.zeros_like(P)
+        ops.adam_step(P, G, M, V, 1, lr=1e-4)
+        ref = g["adam1/" + k].reshape(-1)
+        # Adam normalises by sqrt(v): entries whose gradient is round-off noise (|g| ~ 1e-9) move by +-lr either way
+        big = np.abs(g["grad/" + k].reshape(-1)) > 1e-6 * np.abs(g["grad/" + k]).max()
+        assert np.abs(P.cpu().numpy() - ref)[big].max() <= 2e-6, k

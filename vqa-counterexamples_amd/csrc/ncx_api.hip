@@ -1,0 +1,755 @@
+// ncx_api.hip -- C ABI of libneuralcx_hip.so (include/neuralcx.h) and the bandwidth-bound kernels around
+// the segmented MFMA GEMM engine (ncx_gemm.h).  gfx950 only.
+//
+// Forward of one batch (B triplets x K candidates, M = B*K rows), replacing vqa/models/cx.py:279-331:
+//   k_prep           per row (b,k): feature-table row ids, ||v_o - v_k + 1e-6||_2 (cx.py:300), rank one-hot
+//                    (cx.py:304-305) and the softmax statistics of a_knns[b,k,:] (cx.py:281)          [HBM]
+//   Gt   = W1[:, a_emb_other] . E^T      [H, A]   re-association of K3: softmax(a).E.W^T = softmax(a).(E.W^T) [MFMA]
+//   Sh   = b1 + [v_o | q | z_o | E[aid]] . W1[:, shared cols]^T      [B, H]  once per triplet        [MFMA]
+//   h1   = drop(relu(Sh[b] + [v_k | v_o*v_k | dist,rank | z_k | softmax(a_k)] . [W1 slices | Gt]^T)) [MFMA]
+//   h2, h3 (L >= 2), scores = h_L . w_out + b_out                                                     [MFMA/HBM]
+// Backward mirrors it (see ncx_backward).  Nothing here allocates or synchronises.
+#include "ncx_internal.h"
+#include <stdlib.h>
+
+namespace ncx {
+
+// =================================================================================================
+// small kernels
+// =================================================================================================
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// One wave per logical row r = b*K + k.  4 rows per 256-thread block.
+__global__ __launch_bounds__(256) void k_prep(ncx_dims d, ncx_inputs in, int* __restrict__ idx_k,
+                                              int* __restrict__ idx_o, int* __restrict__ idx_ob,
+                                              float* __restrict__ mx, float* __restrict__ inv,
+                                              float* __restrict__ misc) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int M = d.B * d.K;
+    if (r >= M) return;
+    const int b = r / d.K, k = r - b * d.K;
+    const int io = in.img_idx[(long long)b * (d.K + 1)];
+    const int ik = in.img_idx[(long long)b * (d.K + 1) + 1 + k];
+    if (lane == 0) { idx_o[r] = io; idx_k[r] = ik; if (k == 0) idx_ob[b] = io; }
+
+    float dist = 0.f;
+    if (d.flags & NCX_F_V_DIST) {
+        const float* vo = in.feats + (long long)io * d.dv;
+        const float* vk = in.feats + (long long)ik * d.dv;
+        float s = 0.f;
+        for (int c = lane * 4; c < d.dv; c += 256) {
+            const f32x4 a = load4(vo, c, d.dv), e = load4(vk, c, d.dv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c + j < d.dv) { const float t = a[j] - e[j] + 1e-6f; s += t * t; }
+        }
+        dist = sqrtf(wave_sum(s));
+    }
+    const int mw = d.K + 1;
+    float* mrow = misc + (long long)r * mw;
+    if (lane == 0) mrow[0] = dist;
+    for (int j = lane; j < d.K; j += 64)
+        mrow[1 + j] = (d.flags & NCX_F_V_RANK) ? (j == k ? 1.f : 0.f) : in.v_rank[((long long)r) * d.K + j];
+
+    if (d.flags & NCX_F_A_EMB) {
+        const float* a = in.a_knns + (long long)r * d.A;
+        float m = -INFINITY;
+        for (int c = lane * 4; c < d.A; c += 256) {
+            const f32x4 v = load4(a, c, d.A);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (c + j < d.A) m = fmaxf(m, v[j]);
+        }
+        m = wave_max(m);
+        float s = 0.f;
+        for (int c = lane * 4; c < d.A; c += 256) {
+            const f32x4 v = load4(a, c, d.A);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (c + j < d.A) s += __expf(v[j] - m);
+        }
+        s = wave_sum(s);
+        if (lane == 0) { mx[r] = m; inv[r] = 1.f / s; }
+    }
+}
+
+// scores[r] = h[r,:] . w + b     (cx.py:327); one wave per row.
+__global__ __launch_bounds__(256) void k_scores(const float* __restrict__ h, const float* __restrict__ w,
+                                                const float* __restrict__ bias, float* __restrict__ scores,
+                                                int M, int H) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const float* row = h + (long long)r * H;
+    float s = 0.f;
+    for (int c = lane * 4; c < H; c += 256) {
+        const f32x4 a = load4(row, c, H), e = load4(w, c, H);
+        s += a[0] * e[0] + a[1] * e[1] + a[2] * e[2] + a[3] * e[3];
+    }
+    s = wave_sum(s);
+    if (lane == 0) scores[r] = s + bias[0];
+}
+
+// Listwise softmax cross-entropy over the K candidates of a triplet + rank of the ground truth.
+// One wave per triplet, lane k holds score k (K <= 64).
+__global__ __launch_bounds__(256) void k_loss_rank(const float* __restrict__ scores, const int* __restrict__ gt,
+                                                   int B, int K, float scale, float* __restrict__ loss_rows,
+                                                   float* __restrict__ dscores, int* __restrict__ rank) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float s = lane < K ? scores[(long long)b * K + lane] : -INFINITY;
+    const int g = gt[b];
+    const float m = wave_max(s);
+    const float e = lane < K ? __expf(s - m) : 0.f;
+    const float sum = wave_sum(e);
+    const float sg = __shfl(s, g, 64);
+    if (dscores && lane < K) dscores[(long long)b * K + lane] = (e / sum - (lane == g ? 1.f : 0.f)) * scale;
+    const bool ahead = lane < K && (s > sg || (s == sg && lane < g));
+    const unsigned long long bal = __ballot(ahead);
+    if (lane == 0) {
+        if (loss_rows) loss_rows[b] = (logf(sum) + m - sg) * scale;
+        if (rank) rank[b] = __popcll(bal);
+    }
+}
+
+// loss = sum(loss_rows); hits = {#rank<1, #rank<5}.  Single block: deterministic.
+__global__ __launch_bounds__(256) void k_loss_finish(const float* __restrict__ loss_rows, const int* __restrict__ rank,
+                                                     int B, float* __restrict__ loss, int* __restrict__ hits) {
+    __shared__ float sl[4];
+    __shared__ int s1[4], s5[4];
+    float acc = 0.f; int h1 = 0, h5 = 0;
+    for (int i = threadIdx.x; i < B; i += 256) {
+        if (loss_rows) acc += loss_rows[i];
+        if (rank) { const int rk = rank[i]; h1 += rk < 1; h5 += rk < 5; }
+    }
+    acc = wave_sum(acc);
+    h1 = (int)wave_sum((float)h1); h5 = (int)wave_sum((float)h5);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sl[w] = acc; s1[w] = h1; s5[w] = h5; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (loss) loss[0] = sl[0] + sl[1] + sl[2] + sl[3];
+        if (hits) { hits[0] = s1[0] + s1[1] + s1[2] + s1[3]; hits[1] = s5[0] + s5[1] + s5[2] + s5[3]; }
+    }
+}
+
+// dpre[r,n] = gs[r] * w_out[n] * (h[r,n] > 0 ? scale : 0)          (backward of out + dropout + relu)
+__global__ __launch_bounds__(256) void k_dpre_last(const float* __restrict__ gs, const float* __restrict__ w_out,
+                                                   const float* __restrict__ h, float* __restrict__ dpre,
+                                                   long long total, int H, float scale) {
+    long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= total) return;
+    const int r = (int)(i / H), n = (int)(i - (long long)r * H);
+    if (n + 3 < H && i + 3 < total) {
+        const f32x4 hv = *(const f32x4u*)(h + i);
+        const f32x4 wv = *(const f32x4u*)(w_out + n);
+        const float g = gs[r];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = hv[j] > 0.f ? g * wv[j] * scale : 0.f;
+        *(f32x4u*)(dpre + i) = o;
+    } else {
+        for (int j = 0; j < 4 && i + j < total; ++j) {
+            const int rr = (int)((i + j) / H), nn = (int)((i + j) - (long long)rr * H);
+            dpre[i + j] = h[i + j] > 0.f ? gs[rr] * w_out[nn] * scale : 0.f;
+        }
+    }
+}
+
+// partial[ch][n] = sum over rows of chunk ch of x[r][n] (* wgt[r]);  finish sums the chunks.
+__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ x, const float* __restrict__ wgt,
+                                                        int M, int N, float* __restrict__ partial) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int ch = blockIdx.y, nch = gridDim.y;
+    if (n >= N) return;
+    const int r0 = (int)((long long)M * ch / nch), r1 = (int)((long long)M * (ch + 1) / nch);
+    float s = 0.f;
+    if (wgt) for (int r = r0; r < r1; ++r) s += x[(long long)r * N + n] * wgt[r];
+    else     for (int r = r0; r < r1; ++r) s += x[(long long)r * N + n];
+    partial[(long long)ch * N + n] = s;
+}
+__global__ __launch_bounds__(256) void k_colsum_finish(const float* __restrict__ partial, int nch, int N,
+                                                       float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int c = 0; c < nch; ++c) s += partial[(long long)c * N + n];
+    out[n] = s;
+}
+// out[0] = sum(x[0..n)); single block.
+__global__ __launch_bounds__(256) void k_sum_vec(const float* __restrict__ x, int n, float* __restrict__ out) {
+    __shared__ float sl[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += x[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sl[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = sl[0] + sl[1] + sl[2] + sl[3];
+}
+
+// dsh[b][n] = sum_k dpre[b*K + k][n]
+__global__ __launch_bounds__(256) void k_rowgroup_sum(const float* __restrict__ dpre, int B, int K, int H,
+                                                      float* __restrict__ dsh) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * H) return;
+    const int b = (int)(i / H), n = (int)(i - (long long)b * H);
+    const float* p = dpre + (long long)b * K * H + n;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += p[(long long)k * H];
+    dsh[i] = s;
+}
+
+// Sum split-K slabs and scatter the column ranges to their destinations (+ optional bias per column).
+struct ReduceRange { const float* src; float* dst; const float* bias; long long lds, ldd; int cols; int col0; };
+struct ReduceArgs { ReduceRange r[NCX_MAX_SEG]; int nr; int rows; int ksplit; long long split_stride; int total_cols; };
+__global__ __launch_bounds__(256) void k_slab_reduce(const ReduceArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)a.rows * a.total_cols) return;
+    const int row = (int)(i / a.total_cols);
+    int c = (int)(i - (long long)row * a.total_cols);
+    int q = 0;
+    while (q + 1 < a.nr && c >= a.r[q + 1].col0) ++q;
+    c -= a.r[q].col0;
+    const float* s = a.r[q].src + (long long)row * a.r[q].lds + c;
+    float v = a.r[q].bias ? a.r[q].bias[c] : 0.f;
+    for (int z = 0; z < a.ksplit; ++z) v += s[(long long)z * a.split_stride];
+    a.r[q].dst[(long long)row * a.r[q].ldd + c] = v;
+}
+
+// dst[aid[b]][:] += src[b][:], deterministically: the first occurrence of an id owns the row and adds
+// every duplicate in batch order (cx.py:280 backward: embedding scatter-add).
+__global__ __launch_bounds__(256) void k_scatter_rows_dedup(const float* __restrict__ src, const int* __restrict__ aid,
+                                                            int B, int W, float* __restrict__ dst) {
+    const int b = blockIdx.x;
+    const int id = aid[b];
+    for (int j = 0; j < b; ++j) if (aid[j] == id) return;      // not the owner (uniform per block)
+    for (int c = threadIdx.x; c < W; c += 256) {
+        float s = dst[(long long)id * W + c];
+        for (int j = b; j < B; ++j) if (aid[j] == id) s += src[(long long)j * W + c];
+        dst[(long long)id * W + c] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_zero_cols(float* __restrict__ p, int rows, long long ld, int cols) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i - (long long)r * cols);
+    p[(long long)r * ld + c] = 0.f;
+}
+
+// torch.optim.Adam (counterexamples.py:275-276): m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g^2;
+// p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps).
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, size_t n, float step_size, float b1, float b2,
+                                              float eps, float inv_bc2_sqrt, float gscale) {
+    size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (; i < n; i += stride) {
+        if (i + 3 < n) {
+            f32x4 pv = *(f32x4*)(p + i), gv = *(const f32x4*)(g + i), mv = *(f32x4*)(m + i), vv = *(f32x4*)(v + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float gj = gv[j] * gscale;
+                mv[j] = mv[j] + (gj - mv[j]) * (1.f - b1);
+                vv[j] = vv[j] * b2 + (1.f - b2) * gj * gj;
+                const float den = sqrtf(vv[j]) * inv_bc2_sqrt + eps;
+                pv[j] = pv[j] - step_size * (mv[j] / den);
+            }
+            *(f32x4*)(p + i) = pv; *(f32x4*)(m + i) = mv; *(f32x4*)(v + i) = vv;
+        } else {
+            for (size_t j = i; j < n; ++j) {
+                const float gj = g[j] * gscale;
+                const float mj = m[j] + (gj - m[j]) * (1.f - b1);
+                const float vj = v[j] * b2 + (1.f - b2) * gj * gj;
+                m[j] = mj; v[j] = vj;
+                p[j] = p[j] - step_size * (mj / (sqrtf(vj) * inv_bc2_sqrt + eps));
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// planning
+// =================================================================================================
+static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
+
+// tiles_big / tiles_small: output tiles with 128x128 / 64x64 blocks; ksteps: 32-deep reduction steps.
+static GemmPlan plan_from_tiles(long long tiles_big, long long tiles_small, long long ksteps, bool big_ok) {
+    const long long target = 512;                        // ~2 resident workgroups per CU
+    const long long max_split = ksteps / 4 > 1 ? ksteps / 4 : 1;
+    GemmPlan p;
+    if (big_ok && tiles_big >= 160) { p.cfg = CFG_128x128; p.ksplit = 1; return p; }
+    long long sb = cdiv(target, tiles_big);   if (sb > max_split) sb = max_split;
+    long long ss = cdiv(target, tiles_small); if (ss > max_split) ss = max_split;
+    if (ss > 64) ss = 64;
+    if (sb > 64) sb = 64;
+    if (big_ok && tiles_big * sb >= 256) { p.cfg = CFG_128x128; p.ksplit = (int)sb; return p; }
+    p.cfg = CFG_64x64; p.ksplit = (int)ss;
+    return p;
+}
+
+GemmPlan plan_gemm(int form, long long M, long long N, long long ksteps, bool allow_96) {
+    if (form == FORM_NT && allow_96 && M % 96 == 0 && N % 128 == 0 && (M / 96) * (N / 128) >= 192 &&
+        (M % 128 != 0 || cdiv(M, 128) * cdiv(N, 128) < 256)) {
+        GemmPlan p; p.cfg = CFG_96x128; p.ksplit = 1; return p;
+    }
+    const bool big_ok = M >= 96 && N >= 96;
+    return plan_from_tiles(cdiv(M, 128) * cdiv(N, 128), cdiv(M, 64) * cdiv(N, 64), ksteps, big_ok);
+}
+
+// The GEMMs of one step, so that ws_layout and forward/backward agree on split-K slab sizes.
+struct GemmUse { int form; long long M, N, ksteps; bool allow96; GemmPlan plan; long long slab_elems; };
+enum { U_GT = 0, U_SH, U_MAIN, U_FWD_L, U_DW1C, U_DW1S, U_DE, U_DW1AK, U_DAGT, U_DWL, U_DXL, U_COUNT };
+
+static inline long long ks(long long k) { return cdiv(k, GEMM_BK); }
+
+static void list_uses(const ncx_dims& d, GemmUse* u) {
+    const long long M = (long long)d.B * d.K, H = d.H;
+    const bool aemb = d.flags & NCX_F_A_EMB;
+    const long long cand_k = ks(d.dv) * ((d.flags & NCX_F_V_MULT) ? 2 : 1) + ks(d.K + 1) + ks(d.dz) + (aemb ? ks(d.A) : ks(d.da));
+    const long long cand_cols = (long long)d.dv * ((d.flags & NCX_F_V_MULT) ? 2 : 1) + d.K + 1 + d.dz + (aemb ? d.A : d.da);
+    const long long sh_k = ks(d.dv) + ks(d.dq) + ks(d.dz) + ks(d.da);
+    const long long sh_cols = (long long)d.dv + d.dq + d.dz + d.da;
+    u[U_GT]    = {FORM_NT, H, d.A, ks(d.da), false};
+    u[U_SH]    = {FORM_NT, d.B, H, sh_k, false};
+    u[U_MAIN]  = {FORM_NT, M, H, cand_k, true};
+    u[U_FWD_L] = {FORM_NT, M, H, ks(H), true};
+    u[U_DW1C]  = {FORM_TN, H, cand_cols, ks(M), false};
+    u[U_DW1S]  = {FORM_TN, H, sh_cols, ks(d.B), false};
+    u[U_DE]    = {FORM_TN, d.A, d.da, ks(H), false};
+    u[U_DW1AK] = {FORM_NN, H, d.da, ks(d.A), false};
+    u[U_DAGT]  = {FORM_NN, d.B, d.da, ks(H), false};
+    u[U_DWL]   = {FORM_TN, H, H, ks(M), false};
+    u[U_DXL]   = {FORM_NN, M, H, ks(H), false};
+    for (int i = 0; i < U_COUNT; ++i) {
+        u[i].plan = plan_gemm(u[i].form, u[i].M, u[i].N, u[i].ksteps, u[i].allow96);
+        if (i == U_MAIN || i == U_FWD_L || i == U_DXL) u[i].plan.ksplit = 1;   // epilogue GEMMs never split
+        u[i].slab_elems = u[i].plan.ksplit > 1 ? (long long)u[i].plan.ksplit * u[i].M * u[i].N : 0;
+    }
+}
+
+WsLayout ws_layout(const ncx_dims& d) {
+    WsLayout w{};
+    const size_t M = (size_t)d.B * d.K, H = d.H;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    w.idx_k = take(M * 4); w.idx_o = take(M * 4); w.idx_ob = take((size_t)d.B * 4);
+    w.mx = take(M * 4); w.inv = take(M * 4);
+    w.misc = take(M * (d.K + 1) * 4);
+    w.gt = take(H * d.A * 4);
+    w.sh = take((size_t)d.B * H * 4);
+    for (int l = 0; l < 3; ++l) w.h[l] = l < d.L ? take(M * H * 4) : 0;
+    w.dpre[0] = take(M * H * 4);
+    w.dpre[1] = d.L >= 2 ? take(M * H * 4) : 0;
+    w.dsh = take((size_t)d.B * H * 4);
+    w.dgt = take(H * d.A * 4);
+    w.dagt = take((size_t)d.B * d.da * 4);
+    w.partial = take((size_t)NCX_COLSUM_CHUNKS * H * 4 * 2 + 256);
+    GemmUse u[U_COUNT];
+    list_uses(d, u);
+    long long slab = 0;
+    for (int i = 0; i < U_COUNT; ++i) slab = u[i].slab_elems > slab ? u[i].slab_elems : slab;
+    w.slab_bytes = (size_t)slab * 4;
+    w.slab = take(w.slab_bytes);
+    w.total = off;
+    return w;
+}
+
+static int check_dims(const ncx_dims* d) {
+    if (!d) return NCX_E_NULL;
+    if (d->B < 1 || d->K < 1 || d->K > 64 || d->dv < 1 || d->dq < 1 || d->dz < 1 || d->da < 1 || d->A < 1 ||
+        d->H < 1 || d->L < 1 || d->L > 3 || d->n_img < 1)
+        return NCX_E_DIMS;
+    if ((long long)d->B * d->K > (1ll << 30) / 4) return NCX_E_DIMS;
+    if (d->drop_p < 0.f || d->drop_p >= 1.f) return NCX_E_DIMS;
+    return NCX_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// Opt-in diagnostics (ncx_profile_begin/_end): HIP events around every launch of ONE chosen GEMM, on the
+// stream it is launched on.  Off by default; the only process-global state of the library.
+// -------------------------------------------------------------------------------------------------
+struct ProfState { bool on; int id, n, cap; hipEvent_t* ev; };
+static ProfState g_prof = {false, -1, 0, 0, nullptr};
+
+static int run_gemm_impl(GemmArgs& a, int form, const GemmPlan& pl, float* slab, size_t slab_bytes,
+                         const float* reduce_bias, hipStream_t s);
+
+// GEMM driver: runs `a` with plan `pl`; when split, redirects the outputs to slabs and reduces them.
+static int run_gemm(int use_id, GemmArgs& a, int form, const GemmPlan& pl, float* slab, size_t slab_bytes,
+                    const float* reduce_bias, hipStream_t s) {
+    const bool rec = g_prof.on && g_prof.id == use_id && g_prof.n < g_prof.cap;
+    if (rec) NCX_HIP_TRY(hipEventRecord(g_prof.ev[2 * g_prof.n], s));
+    const int rc = run_gemm_impl(a, form, pl, slab, slab_bytes, reduce_bias, s);
+    if (rec) { NCX_HIP_TRY(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s)); ++g_prof.n; }
+    return rc;
+}
+
+static int run_gemm_impl(GemmArgs& a, int form, const GemmPlan& pl, float* slab, size_t slab_bytes,
+                         const float* reduce_bias, hipStream_t s) {
+    a.ksplit = pl.ksplit;
+    ReduceArgs ra{};
+    if (pl.ksplit > 1) {
+        const int np = a.mode == MODE_GROUP ? a.nseg : 1;
+        long long total_cols = 0;
+        for (int i = 0; i < np; ++i) total_cols += a.n_cols[i];
+        const long long per_slab = (long long)a.M * total_cols;
+        if ((size_t)(per_slab * pl.ksplit * 4) > slab_bytes) return NCX_E_WORKSPACE;
+        long long c0 = 0;
+        for (int i = 0; i < np; ++i) {
+            ra.r[i].src = slab + c0; ra.r[i].lds = total_cols;
+            ra.r[i].dst = a.out[i]; ra.r[i].ldd = a.ldo[i];
+            ra.r[i].cols = a.n_cols[i]; ra.r[i].col0 = (int)c0;
+            ra.r[i].bias = reduce_bias;
+            a.out[i] = slab + c0; a.ldo[i] = total_cols;
+            c0 += a.n_cols[i];
+        }
+        ra.nr = np; ra.rows = a.M; ra.ksplit = pl.ksplit; ra.split_stride = per_slab; ra.total_cols = (int)total_cols;
+        a.split_stride = per_slab;
+    }
+    int rc;
+    if (form == FORM_NT) rc = run_gemm_nt(a, pl.cfg, s);
+    else if (form == FORM_TN) rc = run_gemm_tn(a, pl.cfg, s);
+    else rc = run_gemm_nn(a, pl.cfg, s);
+    if (rc != 0) return rc;
+    if (pl.ksplit > 1) {
+        const long long n = (long long)ra.rows * ra.total_cols;
+        hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, ra);
+        NCX_HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+static void set_dropout(EpiArgs& e, const ncx_dims& d, const ncx_inputs& in, int layer, long long M) {
+    e.relu = 1;
+    if (d.training && d.drop_p > 0.f) {
+        e.drop_p = d.drop_p; e.drop_scale = 1.f / (1.f - d.drop_p);
+        if (in.keep_mask) { e.dropout = 2; e.keep_mask = in.keep_mask + (long long)(layer - 1) * M * d.H; e.ld_mask = d.H; }
+        else { e.dropout = 1; e.seed_lo = (unsigned)(d.seed & 0xFFFFFFFFull); e.seed_hi = (unsigned)(d.seed >> 32); e.layer = (unsigned)layer; }
+    }
+}
+
+}  // namespace ncx
+
+using namespace ncx;
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+const char* ncx_version(void) { return "neuralcx-hip gfx950 fp32-mfma r1 (" __DATE__ ")"; }
+
+int64_t ncx_input_size(const ncx_dims* d) { return d ? (int64_t)seg_offsets(*d).din : 0; }
+
+size_t ncx_workspace_bytes(const ncx_dims* d) {
+    if (check_dims(d) != NCX_OK) return 0;
+    return ws_layout(*d).total;
+}
+
+int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, void* workspace,
+                size_t workspace_bytes, float* scores, void* stream_) {
+    int rc = check_dims(dp);
+    if (rc != NCX_OK) return rc;
+    if (!in || !p || !workspace || !scores) return NCX_E_NULL;
+    const ncx_dims& d = *dp;
+    const bool aemb = d.flags & NCX_F_A_EMB;
+    if (!in->feats || !in->img_idx || !in->q_emb || !in->z_orig || !in->z_knns || !in->a_knns) return NCX_E_NULL;
+    if (aemb && (!in->answer_aids || !p->answer_embedding)) return NCX_E_NULL;
+    if (!aemb && !in->a_emb_gt) return NCX_E_FLAGS;
+    if (!(d.flags & NCX_F_V_RANK) && !in->v_rank) return NCX_E_FLAGS;
+    if (!p->w1 || !p->b1 || !p->w_out || !p->b_out) return NCX_E_NULL;
+    if (d.L >= 2 && (!p->w2 || !p->b2)) return NCX_E_NULL;
+    if (d.L >= 3 && (!p->w3 || !p->b3)) return NCX_E_NULL;
+    const WsLayout w = ws_layout(d);
+    if (workspace_bytes < w.total || ((uintptr_t)workspace & 255)) return NCX_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    const int M = d.B * d.K, H = d.H;
+    const SegOffsets o = seg_offsets(d);
+    const long long din = o.din;
+    int* idx_k = (int*)(ws + w.idx_k); int* idx_o = (int*)(ws + w.idx_o); int* idx_ob = (int*)(ws + w.idx_ob);
+    float* mx = (float*)(ws + w.mx); float* inv = (float*)(ws + w.inv); float* misc = (float*)(ws + w.misc);
+    float* gt = (float*)(ws + w.gt); float* sh = (float*)(ws + w.sh); float* slab = (float*)(ws + w.slab);
+    GemmUse u[U_COUNT];
+    list_uses(d, u);
+
+    hipLaunchKernelGGL(k_prep, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, s, d, *in, idx_k, idx_o, idx_ob, mx, inv, misc);
+    NCX_HIP_TRY(hipGetLastError());
+
+    // Gt[H, A] = W1[:, a_other] . E^T
+    if (aemb) {
+        GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = H;
+        a.a[0] = x_plain(p->w1 + o.a_other, din, H, d.da);
+        a.b[0] = x_plain(p->answer_embedding, d.da, d.A, d.da);
+        a.klen[0] = d.da; a.out[0] = gt; a.ldo[0] = d.A; a.n_cols[0] = d.A;
+        rc = run_gemm(U_GT, a, FORM_NT, u[U_GT].plan, slab, w.slab_bytes, nullptr, s);
+        if (rc) return rc;
+    }
+    // Sh[B, H] = b1 + shared segments
+    {
+        GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 4; a.M = d.B;
+        a.a[0] = x_gather(in->feats, d.dv, idx_ob, d.B, d.dv);  a.b[0] = x_plain(p->w1 + o.v_orig, din, H, d.dv); a.klen[0] = d.dv;
+        a.a[1] = x_plain(in->q_emb, d.dq, d.B, d.dq);            a.b[1] = x_plain(p->w1 + o.q_emb, din, H, d.dq);  a.klen[1] = d.dq;
+        a.a[2] = x_plain(in->z_orig, d.dz, d.B, d.dz);           a.b[2] = x_plain(p->w1 + o.z_orig, din, H, d.dz); a.klen[2] = d.dz;
+        a.a[3] = aemb ? x_gather(p->answer_embedding, d.da, in->answer_aids, d.B, d.da)
+                      : x_plain(in->a_emb_gt, d.da, d.B, d.da);
+        a.b[3] = x_plain(p->w1 + o.a_gt, din, H, d.da); a.klen[3] = d.da;
+        a.out[0] = sh; a.ldo[0] = H; a.n_cols[0] = H;
+        GemmPlan pl = u[U_SH].plan;
+        if (pl.ksplit > 1) {
+            rc = run_gemm(U_SH, a, FORM_NT, pl, slab, w.slab_bytes, p->b1, s);
+        } else {
+            a.epi.bias = p->b1;
+            rc = run_gemm(U_SH, a, FORM_NT, pl, slab, w.slab_bytes, nullptr, s);
+        }
+        if (rc) return rc;
+    }
+    // h1 = drop(relu(Sh[b] + candidate segments))
+    {
+        GemmArgs a{}; a.mode = MODE_CHAIN; a.M = M;
+        int n = 0;
+        a.a[n] = x_gather(in->feats, d.dv, idx_k, M, d.dv); a.b[n] = x_plain(p->w1 + o.v_other, din, H, d.dv); a.klen[n] = d.dv; ++n;
+        if (d.flags & NCX_F_V_MULT) {
+            a.a[n] = x_gather_mul(in->feats, d.dv, idx_k, idx_o, M, d.dv); a.b[n] = x_plain(p->w1 + o.v_mult, din, H, d.dv); a.klen[n] = d.dv; ++n;
+        }
+        a.a[n] = x_plain(misc, d.K + 1, M, d.K + 1); a.b[n] = x_plain(p->w1 + o.v_dist, din, H, d.K + 1); a.klen[n] = d.K + 1; ++n;
+        a.a[n] = x_plain(in->z_knns, d.dz, M, d.dz); a.b[n] = x_plain(p->w1 + o.z_other, din, H, d.dz); a.klen[n] = d.dz; ++n;
+        if (aemb) { a.a[n] = x_softmax(in->a_knns, d.A, mx, inv, M, d.A); a.b[n] = x_plain(gt, d.A, H, d.A); a.klen[n] = d.A; ++n; }
+        else      { a.a[n] = x_plain(in->a_knns, d.da, M, d.da); a.b[n] = x_plain(p->w1 + o.a_other, din, H, d.da); a.klen[n] = d.da; ++n; }
+        a.nseg = n;
+        a.out[0] = (float*)(ws + w.h[0]); a.ldo[0] = H; a.n_cols[0] = H;
+        a.epi.rowadd = sh; a.epi.ld_rowadd = H; a.epi.rowdiv = d.K;
+        set_dropout(a.epi, d, *in, 1, M);
+        rc = run_gemm(U_MAIN, a, FORM_NT, u[U_MAIN].plan, slab, w.slab_bytes, nullptr, s);
+        if (rc) return rc;
+    }
+    for (int l = 2; l <= d.L; ++l) {
+        const float* wl = l == 2 ? p->w2 : p->w3;
+        const float* bl = l == 2 ? p->b2 : p->b3;
+        GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = M;
+        a.a[0] = x_plain((const float*)(ws + w.h[l - 2]), H, M, H); a.b[0] = x_plain(wl, H, H, H); a.klen[0] = H;
+        a.out[0] = (float*)(ws + w.h[l - 1]); a.ldo[0] = H; a.n_cols[0] = H;
+        a.epi.bias = bl;
+        set_dropout(a.epi, d, *in, l, M);
+        rc = run_gemm(U_FWD_L, a, FORM_NT, u[U_FWD_L].plan, slab, w.slab_bytes, nullptr, s);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_scores, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, s, (const float*)(ws + w.h[d.L - 1]),
+                       p->w_out, p->b_out, scores, M, H);
+    NCX_HIP_TRY(hipGetLastError());
+    return NCX_OK;
+}
+
+int ncx_loss_rank(const float* scores, const int32_t* gt, int32_t B, int32_t K, float scale, float* loss_rows,
+                  float* loss, float* dscores, int32_t* rank, int32_t* hits, void* stream_) {
+    if (!scores || !gt) return NCX_E_NULL;
+    if (B < 1 || K < 1 || K > 64) return NCX_E_DIMS;
+    if ((loss && !loss_rows) || (hits && !rank)) return NCX_E_NULL;
+    hipStream_t s = (hipStream_t)stream_;
+    if (scale <= 0.f) scale = 1.f / (float)B;
+    hipLaunchKernelGGL(k_loss_rank, dim3((unsigned)cdiv(B, 4)), dim3(256), 0, s, scores, gt, B, K, scale, loss_rows, dscores, rank);
+    NCX_HIP_TRY(hipGetLastError());
+    if (loss || hits) {
+        hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, s, (const float*)loss_rows, (const int*)rank, B, loss, hits);
+        NCX_HIP_TRY(hipGetLastError());
+    }
+    return NCX_OK;
+}
+
+int ncx_backward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, void* workspace,
+                 size_t workspace_bytes, const float* dscores, const ncx_grads* g, void* stream_) {
+    int rc = check_dims(dp);
+    if (rc != NCX_OK) return rc;
+    if (!in || !p || !workspace || !dscores || !g) return NCX_E_NULL;
+    const ncx_dims& d = *dp;
+    const bool aemb = d.flags & NCX_F_A_EMB;
+    if (!g->answer_embedding || !g->w1 || !g->b1 || !g->w_out || !g->b_out) return NCX_E_NULL;
+    if (d.L >= 2 && (!g->w2 || !g->b2)) return NCX_E_NULL;
+    if (d.L >= 3 && (!g->w3 || !g->b3)) return NCX_E_NULL;
+    const WsLayout w = ws_layout(d);
+    if (workspace_bytes < w.total || ((uintptr_t)workspace & 255)) return NCX_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    const int M = d.B * d.K, H = d.H;
+    const SegOffsets o = seg_offsets(d);
+    const long long din = o.din;
+    const int* idx_k = (const int*)(ws + w.idx_k); const int* idx_o = (const int*)(ws + w.idx_o);
+    const int* idx_ob = (const int*)(ws + w.idx_ob);
+    const float* mx = (const float*)(ws + w.mx); const float* inv = (const float*)(ws + w.inv);
+    const float* misc = (const float*)(ws + w.misc); const float* gt = (const float*)(ws + w.gt);
+    float* dsh = (float*)(ws + w.dsh); float* dgt = (float*)(ws + w.dgt); float* dagt = (float*)(ws + w.dagt);
+    float* partial = (float*)(ws + w.partial); float* slab = (float*)(ws + w.slab);
+    (void)gt;
+    GemmUse u[U_COUNT];
+    list_uses(d, u);
+    const float dscale = (d.training && d.drop_p > 0.f) ? 1.f / (1.f - d.drop_p) : 1.f;
+    const int nch = M < NCX_COLSUM_CHUNKS * 8 ? (int)cdiv(M, 8) : NCX_COLSUM_CHUNKS;
+
+    auto colsum = [&](const float* x, const float* wgt, int rows, int cols, float* out) -> int {
+        const int ch = rows < NCX_COLSUM_CHUNKS * 8 ? (int)cdiv(rows, 8) : NCX_COLSUM_CHUNKS;
+        hipLaunchKernelGGL(k_colsum_partial, dim3((unsigned)cdiv(cols, 256), ch), dim3(256), 0, s, x, wgt, rows, cols, partial);
+        hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)cdiv(cols, 256)), dim3(256), 0, s, (const float*)partial, ch, cols, out);
+        return (int)hipGetLastError();
+    };
+    (void)nch;
+
+    // ---- out layer + last hidden layer's activation ------------------------------------------------
+    const float* hL = (const float*)(ws + w.h[d.L - 1]);
+    float* dpre = (float*)(ws + w.dpre[0]);
+    {
+        const long long total = (long long)M * H;
+        hipLaunchKernelGGL(k_dpre_last, dim3((unsigned)cdiv(total, 1024)), dim3(256), 0, s, dscores, p->w_out, hL, dpre, total, H, dscale);
+        NCX_HIP_TRY(hipGetLastError());
+        rc = colsum(hL, dscores, M, H, g->w_out); if (rc) return rc;
+        hipLaunchKernelGGL(k_sum_vec, dim3(1), dim3(256), 0, s, dscores, M, g->b_out);
+        NCX_HIP_TRY(hipGetLastError());
+    }
+    // ---- hidden layers L..2 ---------------------------------------------------------------------------
+    int cur = 0;
+    for (int l = d.L; l >= 2; --l) {
+        const float* wl = l == 2 ? p->w2 : p->w3;
+        float* gw = l == 2 ? g->w2 : g->w3;
+        float* gb = l == 2 ? g->b2 : g->b3;
+        const float* hprev = (const float*)(ws + w.h[l - 2]);
+        rc = colsum(dpre, nullptr, M, H, gb); if (rc) return rc;
+        {   // dW_l[n][k] = sum_r dpre[r][n] h_{l-1}[r][k]
+            GemmArgs a{}; a.mode = MODE_GROUP; a.nseg = 1; a.M = H;
+            a.a[0] = x_plain(dpre, H, M, H); a.b[0] = x_plain(hprev, H, M, H); a.klen[0] = M;
+            a.out[0] = gw; a.ldo[0] = H; a.n_cols[0] = H;
+            rc = run_gemm(U_DWL, a, FORM_TN, u[U_DWL].plan, slab, w.slab_bytes, nullptr, s); if (rc) return rc;
+        }
+        {   // dpre_{l-1} = (dpre_l . W_l) * gate(h_{l-1})
+            float* dnext = (float*)(ws + w.dpre[cur ^ 1]);
+            GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = M;
+            a.a[0] = x_plain(dpre, H, M, H); a.b[0] = x_plain(wl, H, H, H); a.klen[0] = H;
+            a.out[0] = dnext; a.ldo[0] = H; a.n_cols[0] = H;
+            a.epi.gate = hprev; a.epi.ld_gate = H; a.epi.gate_scale = dscale;
+            rc = run_gemm(U_DXL, a, FORM_NN, u[U_DXL].plan, slab, w.slab_bytes, nullptr, s); if (rc) return rc;
+            dpre = dnext; cur ^= 1;
+        }
+    }
+    // ---- layer 1 ---------------------------------------------------------------------------------------
+    hipLaunchKernelGGL(k_rowgroup_sum, dim3((unsigned)cdiv((long long)d.B * H, 256)), dim3(256), 0, s, (const float*)dpre, d.B, d.K, H, dsh);
+    NCX_HIP_TRY(hipGetLastError());
+    rc = colsum(dsh, nullptr, d.B, H, g->b1); if (rc) return rc;
+    {   // candidate columns of dW1 (+ dGt): dpre^T . X_seg
+        GemmArgs a{}; a.mode = MODE_GROUP; a.M = H;
+        a.a[0] = x_plain(dpre, H, M, H);
+        int n = 0;
+        auto add = [&](const XDesc& x, float* out, long long ldo) { a.b[n] = x; a.klen[n] = M; a.out[n] = out; a.ldo[n] = ldo; a.n_cols[n] = x.cols; ++n; };
+        add(x_gather(in->feats, d.dv, idx_k, M, d.dv), g->w1 + o.v_other, din);
+        if (d.flags & NCX_F_V_MULT) add(x_gather_mul(in->feats, d.dv, idx_k, idx_o, M, d.dv), g->w1 + o.v_mult, din);
+        add(x_plain(misc, d.K + 1, M, d.K + 1), g->w1 + o.v_dist, din);
+        add(x_plain(in->z_knns, d.dz, M, d.dz), g->w1 + o.z_other, din);
+        if (aemb) add(x_softmax(in->a_knns, d.A, mx, inv, M, d.A), dgt, d.A);
+        else      add(x_plain(in->a_knns, d.da, M, d.da), g->w1 + o.a_other, din);
+        a.nseg = n;
+        rc = run_gemm(U_DW1C, a, FORM_TN, u[U_DW1C].plan, slab, w.slab_bytes, nullptr, s); if (rc) return rc;
+        if (!(d.flags & NCX_F_V_MULT)) {
+            hipLaunchKernelGGL(k_zero_cols, dim3((unsigned)cdiv((long long)H * d.dv, 256)), dim3(256), 0, s, g->w1 + o.v_mult, H, din, d.dv);
+            NCX_HIP_TRY(hipGetLastError());
+        }
+    }
+    {   // shared columns of dW1: dSh^T . X_shared
+        GemmArgs a{}; a.mode = MODE_GROUP; a.M = H;
+        a.a[0] = x_plain(dsh, H, d.B, H);
+        int n = 0;
+        auto add = [&](const XDesc& x, float* out) { a.b[n] = x; a.klen[n] = d.B; a.out[n] = out; a.ldo[n] = din; a.n_cols[n] = x.cols; ++n; };
+        add(x_gather(in->feats, d.dv, idx_ob, d.B, d.dv), g->w1 + o.v_orig);
+        add(x_plain(in->q_emb, d.dq, d.B, d.dq), g->w1 + o.q_emb);
+        add(x_plain(in->z_orig, d.dz, d.B, d.dz), g->w1 + o.z_orig);
+        add(aemb ? x_gather(p->answer_embedding, d.da, in->answer_aids, d.B, d.da) : x_plain(in->a_emb_gt, d.da, d.B, d.da),
+            g->w1 + o.a_gt);
+        a.nseg = n;
+        rc = run_gemm(U_DW1S, a, FORM_TN, u[U_DW1S].plan, slab, w.slab_bytes, nullptr, s); if (rc) return rc;
+    }
+    if (aemb) {
+        {   // dE[a][j] = sum_n dGt[n][a] W1ak[n][j]
+            GemmArgs a{}; a.mode = MODE_GROUP; a.nseg = 1; a.M = d.A;
+            a.a[0] = x_plain(dgt, d.A, H, d.A); a.b[0] = x_plain(p->w1 + o.a_other, din, H, d.da); a.klen[0] = H;
+            a.out[0] = g->answer_embedding; a.ldo[0] = d.da; a.n_cols[0] = d.da;
+            rc = run_gemm(U_DE, a, FORM_TN, u[U_DE].plan, slab, w.slab_bytes, nullptr, s); if (rc) return rc;
+        }
+        {   // dW1[:, a_other][n][j] = sum_a dGt[n][a] E[a][j]
+            GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = H;
+            a.a[0] = x_plain(dgt, d.A, H, d.A); a.b[0] = x_plain(p->answer_embedding, d.da, d.A, d.da); a.klen[0] = d.A;
+            a.out[0] = g->w1 + o.a_other; a.ldo[0] = din; a.n_cols[0] = d.da;
+            rc = run_gemm(U_DW1AK, a, FORM_NN, u[U_DW1AK].plan, slab, w.slab_bytes, nullptr, s); if (rc) return rc;
+        }
+        {   // dA_gt[b][j] = sum_n dSh[b][n] W1agt[n][j];  dE[aid[b]] += dA_gt[b]
+            GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = d.B;
+            a.a[0] = x_plain(dsh, H, d.B, H); a.b[0] = x_plain(p->w1 + o.a_gt, din, H, d.da); a.klen[0] = H;
+            a.out[0] = dagt; a.ldo[0] = d.da; a.n_cols[0] = d.da;
+            rc = run_gemm(U_DAGT, a, FORM_NN, u[U_DAGT].plan, slab, w.slab_bytes, nullptr, s); if (rc) return rc;
+            hipLaunchKernelGGL(k_scatter_rows_dedup, dim3(d.B), dim3(256), 0, s, (const float*)dagt, in->answer_aids, d.B, d.da, g->answer_embedding);
+            NCX_HIP_TRY(hipGetLastError());
+        }
+    } else {
+        NCX_HIP_TRY(hipMemsetAsync(g->answer_embedding, 0, (size_t)d.A * d.da * 4, s));
+    }
+    return NCX_OK;
+}
+
+int ncx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
+                  float beta1, float beta2, float eps, int32_t step, float grad_scale, void* stream_) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq) return NCX_E_NULL;
+    if (step < 1 || n == 0) return NCX_E_DIMS;
+    if (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return NCX_E_WORKSPACE;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    size_t blocks = (n + 1023) / 1024;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, param, grad, exp_avg, exp_avg_sq, n,
+                       step_size, beta1, beta2, eps, inv_bc2_sqrt, grad_scale);
+    NCX_HIP_TRY(hipGetLastError());
+    return NCX_OK;
+}
+
+// ---- diagnostics ---------------------------------------------------------------------------------------
+int ncx_profile_begin(int32_t gemm_id, int32_t max_launches) {
+    if (g_prof.on || gemm_id < 0 || gemm_id >= U_COUNT || max_launches < 1 || max_launches > 4096) return NCX_E_DIMS;
+    g_prof.ev = (hipEvent_t*)malloc(sizeof(hipEvent_t) * 2 * (size_t)max_launches);
+    if (!g_prof.ev) return NCX_E_NULL;
+    for (int i = 0; i < 2 * max_launches; ++i) NCX_HIP_TRY(hipEventCreate(&g_prof.ev[i]));
+    g_prof.id = gemm_id; g_prof.n = 0; g_prof.cap = max_launches; g_prof.on = true;
+    return NCX_OK;
+}
+
+int ncx_profile_end(float* ms, int32_t cap) {
+    if (!g_prof.on) return NCX_E_FLAGS;
+    int n = 0;
+    for (int i = 0; i < g_prof.n; ++i) {
+        if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) break;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) break;
+        if (ms && n < cap) ms[n] = t;
+        ++n;
+    }
+    for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
+    free(g_prof.ev);
+    g_prof.ev = nullptr; g_prof.on = false; g_prof.id = -1; g_prof.n = 0; g_prof.cap = 0;
+    return n < cap ? n : cap;
+}
+
+int ncx_plan_query(const ncx_dims* d, int32_t gemm_id, int32_t* out6) {
+    if (check_dims(d) != NCX_OK || !out6 || gemm_id < 0 || gemm_id >= U_COUNT) return NCX_E_DIMS;
+    GemmUse u[U_COUNT];
+    list_uses(*d, u);
+    out6[0] = u[gemm_id].form; out6[1] = (int32_t)u[gemm_id].M; out6[2] = (int32_t)u[gemm_id].N;
+    out6[3] = (int32_t)u[gemm_id].ksteps; out6[4] = u[gemm_id].plan.cfg; out6[5] = u[gemm_id].plan.ksplit;
+    return NCX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,35 @@
+// ncx_common.h -- shared definitions of the NeuralCX HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/neuralcx.h"
+
+namespace ncx {
+
+#define NCX_HIP_TRY(expr)                                 \
+    do {                                                  \
+        hipError_t e__ = (expr);                          \
+        if (e__ != hipSuccess) return (int)e__;           \
+    } while (0)
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Counter-based dropout generator.  Restated on the host in oracle/ncx_oracle.py:dropout_keep_mask
+// (test infrastructure) -- keep the two in sync.  keep <=> u >= p, u = top 24 bits / 2^24.
+__host__ __device__ __forceinline__ unsigned mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu;
+    x ^= x >> 13; x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ bool dropout_keep(unsigned seed_lo, unsigned seed_hi, unsigned layer,
+                                                      unsigned long long idx, float p) {
+    unsigned x = mix32((unsigned)(idx & 0xFFFFFFFFull) ^ seed_lo);
+    x = mix32(x ^ (unsigned)(idx >> 32) ^ seed_hi ^ (layer * 0x9E3779B9u));
+    const float u = (float)(x >> 8) * (1.0f / 16777216.0f);
+    return u >= p;
+}
+
+}  // namespace ncx

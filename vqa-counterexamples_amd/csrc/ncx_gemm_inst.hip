@@ -1,0 +1,35 @@
+// Explicit instantiations of the segmented GEMM engine (one translation unit per product form keeps
+// the parallel build short).  FORM is defined by the Makefile: 0 = NT, 1 = TN, 2 = NN.
+#include "ncx_gemm.h"
+#include "ncx_internal.h"
+
+namespace ncx {
+
+#if NCX_FORM == 0
+// C[M,N] = sum_p X_p[M,k] . W_p[N,k]^T      (forward layers; both operands col-is-k)
+int run_gemm_nt(GemmArgs& a, int cfg, hipStream_t s) {
+    switch (cfg) {
+    case CFG_128x128: return (int)launch_seg_gemm<128, 128, true, true>(a, s);
+    case CFG_96x128:  return (int)launch_seg_gemm<96, 128, true, true>(a, s);
+    default:          return (int)launch_seg_gemm<64, 64, true, true>(a, s);
+    }
+}
+#elif NCX_FORM == 1
+// C[M,N] = D[k,M]^T . X[k,N]                (weight gradients; both operands row-is-k)
+int run_gemm_tn(GemmArgs& a, int cfg, hipStream_t s) {
+    switch (cfg) {
+    case CFG_128x128: return (int)launch_seg_gemm<128, 128, false, false>(a, s);
+    default:          return (int)launch_seg_gemm<64, 64, false, false>(a, s);
+    }
+}
+#else
+// C[M,N] = D[M,k] . W[k,N]                  (input gradients; A col-is-k, B row-is-k)
+int run_gemm_nn(GemmArgs& a, int cfg, hipStream_t s) {
+    switch (cfg) {
+    case CFG_128x128: return (int)launch_seg_gemm<128, 128, true, false>(a, s);
+    default:          return (int)launch_seg_gemm<64, 64, true, false>(a, s);
+    }
+}
+#endif
+
+}  // namespace ncx

@@ -1,0 +1,59 @@
+// ncx_internal.h -- declarations shared by the translation units of libneuralcx_hip.so.
+#pragma once
+#include "ncx_common.h"
+#include "ncx_gemm.h"
+
+namespace ncx {
+
+enum TileCfg : int { CFG_64x64 = 0, CFG_128x128 = 1, CFG_96x128 = 2 };
+enum GemmForm : int { FORM_NT = 0, FORM_TN = 1, FORM_NN = 2 };
+
+int run_gemm_nt(GemmArgs& a, int cfg, hipStream_t s);
+int run_gemm_tn(GemmArgs& a, int cfg, hipStream_t s);
+int run_gemm_nn(GemmArgs& a, int cfg, hipStream_t s);
+
+// Column offsets of the reference's concat (vqa/models/cx.py:309-320) == layout of linear_1.weight.
+struct SegOffsets {
+    int v_orig, v_other, v_mult, v_dist, v_rank, q_emb, z_orig, z_other, a_gt, a_other, din;
+};
+static inline SegOffsets seg_offsets(const ncx_dims& d) {
+    SegOffsets o; int c = 0;
+    o.v_orig = c;  c += d.dv;
+    o.v_other = c; c += d.dv;
+    o.v_mult = c;  c += d.dv;
+    o.v_dist = c;  c += 1;
+    o.v_rank = c;  c += d.K;
+    o.q_emb = c;   c += d.dq;
+    o.z_orig = c;  c += d.dz;
+    o.z_other = c; c += d.dz;
+    o.a_gt = c;    c += d.da;
+    o.a_other = c; c += d.da;
+    o.din = c;
+    return o;
+}
+
+// Split-K plan of one GEMM: tile config + number of K splits (slabs reduced by k_slab_reduce).
+struct GemmPlan { int cfg; int ksplit; };
+GemmPlan plan_gemm(int form, long long M, long long N, long long ksteps, bool allow_96);
+
+// Workspace partition (byte offsets from a 256-byte aligned base).  Saved-for-backward part first.
+struct WsLayout {
+    size_t idx_k, idx_o, idx_ob;        // int32 [M], [M], [B]: feature-table rows per logical row
+    size_t mx, inv;                     // [M] softmax stats of a_knns rows
+    size_t misc;                        // [M][K+1]: v_dist column + v_rank block (cx.py:299-307)
+    size_t gt;                          // Gt[H][A] = W1[:, a_other] . E^T  (re-associated K3)
+    size_t sh;                          // Sh[B][H]: per-triplet shared part of linear_1 (+ bias)
+    size_t h[3];                        // post-dropout activations of layers 1..L, [M][H]
+    size_t dpre[2];                     // [M][H] ping-pong of pre-activation gradients
+    size_t dsh;                         // [B][H]
+    size_t dgt;                         // [H][A]
+    size_t dagt;                        // [B][da]
+    size_t partial;                     // column-sum partials [NCX_COLSUM_CHUNKS][H] x 2 + scalars
+    size_t slab;                        // split-K slabs (max over all uses)
+    size_t slab_bytes;
+    size_t total;
+};
+constexpr int NCX_COLSUM_CHUNKS = 128;
+WsLayout ws_layout(const ncx_dims& d);
+
+}  // namespace ncx

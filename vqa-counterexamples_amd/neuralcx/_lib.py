@@ -1,0 +1,99 @@
+"""ctypes binding of libneuralcx_hip.so (C ABI: include/neuralcx.h).
+
+This is the stub a maintainer of the reference would add: plain pointers and
+sizes in, status code out.  There is NO fallback: if the HIP library is missing or fails to load,
+importing a symbol raises -- the product path never routes through a CPU implementation.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libneuralcx_hip.so")
+
+NCX_F_V_MULT, NCX_F_V_DIST, NCX_F_V_RANK, NCX_F_A_EMB = 1, 2, 4, 8
+NCX_F_ALL = 15
+
+EXPORTS = ("ncx_input_size", "ncx_workspace_bytes", "ncx_forward", "ncx_loss_rank", "ncx_backward",
+           "ncx_adam_step", "ncx_version", "ncx_profile_begin", "ncx_profile_end", "ncx_plan_query")
+
+
+class NcxDims(C.Structure):
+    _fields_ = [("B", C.c_int32), ("K", C.c_int32), ("dv", C.c_int32), ("dq", C.c_int32),
+                ("dz", C.c_int32), ("da", C.c_int32), ("A", C.c_int32), ("H", C.c_int32),
+                ("L", C.c_int32), ("n_img", C.c_int32), ("flags", C.c_uint32),
+                ("training", C.c_int32), ("drop_p", C.c_float), ("loss_scale", C.c_float),
+                ("seed", C.c_uint64)]
+
+
+class NcxInputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("feats", "img_idx", "q_emb", "z_orig", "z_knns", "a_knns",
+                                           "answer_aids", "a_emb_gt", "v_rank", "keep_mask")]
+
+
+_PNAMES = ("answer_embedding", "w1", "b1", "w2", "b2", "w3", "b3", "w_out", "b_out")
+
+
+class NcxParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _PNAMES]
+
+
+class NcxGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _PNAMES]
+
+
+class NcxError(RuntimeError):
+    pass
+
+
+_ERR = {-1: "NCX_E_NULL (required pointer is NULL)", -2: "NCX_E_DIMS (dimension out of range)",
+        -3: "NCX_E_WORKSPACE (workspace too small or misaligned)", -4: "NCX_E_FLAGS (inconsistent lesion inputs)"}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises with a build hint when it is absent (never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NcxError("HIP library not built: %s is missing. Run `python -c 'import __graft_entry__ as g; "
+                       "g.build()'` or `make -C vqa-counterexamples_amd`." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.ncx_version.restype = C.c_char_p
+    L.ncx_input_size.restype = C.c_int64
+    L.ncx_input_size.argtypes = [C.POINTER(NcxDims)]
+    L.ncx_workspace_bytes.restype = C.c_size_t
+    L.ncx_workspace_bytes.argtypes = [C.POINTER(NcxDims)]
+    L.ncx_forward.restype = C.c_int
+    L.ncx_forward.argtypes = [C.POINTER(NcxDims), C.POINTER(NcxInputs), C.POINTER(NcxParams), C.c_void_p,
+                              C.c_size_t, C.c_void_p, C.c_void_p]
+    L.ncx_loss_rank.restype = C.c_int
+    L.ncx_loss_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ncx_backward.restype = C.c_int
+    L.ncx_backward.argtypes = [C.POINTER(NcxDims), C.POINTER(NcxInputs), C.POINTER(NcxParams), C.c_void_p,
+                               C.c_size_t, C.c_void_p, C.POINTER(NcxGrads), C.c_void_p]
+    L.ncx_adam_step.restype = C.c_int
+    L.ncx_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float,
+                                C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]
+    L.ncx_profile_begin.restype = C.c_int
+    L.ncx_profile_begin.argtypes = [C.c_int32, C.c_int32]
+    L.ncx_profile_end.restype = C.c_int
+    L.ncx_profile_end.argtypes = [C.POINTER(C.c_float), C.c_int32]
+    L.ncx_plan_query.restype = C.c_int
+    L.ncx_plan_query.argtypes = [C.POINTER(NcxDims), C.c_int32, C.POINTER(C.c_int32)]
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc == 0:
+        return
+    if rc < 0:
+        raise NcxError("%s failed: %s" % (what, _ERR.get(rc, rc)))
+    raise NcxError("%s failed: hipError_t %d" % (what, rc))
+
+
+def version():
+    return lib().ncx_version().decode()
