@@ -1,0 +1,190 @@
+#!/usr/bin/env python
+"""bench.py -- NeuralCX training throughput on MI355X (BASELINE.json: "VQA-CX triplets/sec").
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 512] [--H 256] [--L 1] [--K 24]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training pass of the hot path over one batch of synthetic triplets PER RANK
+(forward, listwise loss + recall, backward, [RCCL all-reduce], Adam) with every input resident in HBM.
+Workload at N=1: BASELINE.json configs[1] -- NeuralCX MLP, synthetic 2048-d features, 24 candidates,
+batch 512, H=256, L=1, dropout 0.25, Adam lr 1e-4.  Weak scaling: each rank keeps batch 512.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "vqa-counterexamples_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def usable_cores():
+    """Cores this process may actually use: cgroup quota, else affinity mask (the GPU box exposes 256 logical
+    CPUs but grants a 16-core share per GPU; oversubscribing OpenMP threads there is 100x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    env = os.environ.get("NCX_CPU_THREADS")
+    return int(env) if env else min(n, 16)
+
+
+def cpu_baseline(seconds=15.0):
+    """Reference-faithful CPU path (oracle.FaithfulCPUModel: 24-iteration cat+Linear loop, softmax+bmm,
+    autograd, torch.optim.Adam) at BASELINE configs[0]: B=32, H=256, L=1, full widths.  Bounded sample."""
+    from oracle import ncx_oracle as orc
+    import numpy as np
+    d = orc.Dims()
+    B = 32
+    torch.manual_seed(42)
+    threads = usable_cores()
+    torch.set_num_threads(threads)
+    m = orc.FaithfulCPUModel(d, drop_p=0.25, seed=42)
+    m.train()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    rng = np.random.default_rng(1234)
+    feats = (torch.randn(B, d.K + 1, d.dv).abs() * 0.45)
+    q, zo, zk = torch.randn(B, d.dq) * 0.3, torch.randn(B, d.dz), torch.randn(B, d.K, d.dz)
+    ak = torch.randn(B, d.K, d.A) * 2
+    aid = torch.from_numpy(rng.integers(0, d.A, size=B)); gt = torch.from_numpy(rng.integers(0, d.K, size=B))
+
+    def step():
+        scores = m(feats, q, zo, zk, ak, aid)
+        loss = torch.nn.functional.cross_entropy(scores, gt, reduction="sum") / B
+        opt.zero_grad(); loss.backward(); opt.step()
+    step()                                    # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step(); n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds and n >= 2:
+            break
+    return dict(value=round(B * n / dt, 2), unit="triplets/s", cores=threads, kind="port",
+                sample="%d train steps of batch 32 (configs[0] shapes: K=24, 2048-d feats, H=256, L=1) in %.1f s, "
+                       "torch %s CPU, %d threads" % (n, dt, torch.__version__, threads))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=512, help="triplets per rank per step")
+    ap.add_argument("--H", type=int, default=256)
+    ap.add_argument("--L", type=int, default=1)
+    ap.add_argument("--K", type=int, default=24)
+    ap.add_argument("--n_img", type=int, default=82783)
+    ap.add_argument("--pool", type=int, default=4, help="distinct resident batches cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                             "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
+
+    from neuralcx import _lib
+    from neuralcx.engine import NeuralCXEngine
+    from neuralcx.synth import SyntheticCX
+
+    eng = NeuralCXEngine(K=args.K, H=args.H, L=args.L, drop_p=0.25, lr=1e-4, device=dev, world_size=world)
+    eng.init_parameters(seed=42)                      # identical replicas on every rank
+    data = SyntheticCX(n_triplets=args.batch * args.pool * world, K=args.K, n_img=args.n_img, seed=1234, device=dev)
+    pool = []
+    for i in range(args.pool):                        # rank r owns slice r of every global batch
+        lo = (i * world + rank) * args.batch
+        pool.append(data.batch(torch.arange(lo, lo + args.batch)))
+    gb = args.batch * world
+
+    def step(i):
+        b, gt = pool[i % args.pool]
+        return eng.train_step(b, gt, global_batch=gb)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        r = step(i)
+    fence()
+    if rank == 0:
+        _lib.profile_begin(["MAIN", "DW1C"], max_launches=2 * args.steps + 8)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        r = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    dt = float(t.item())
+    loss = float(r["loss"].item())
+
+    if rank == 0:
+        prof = _lib.profile_end()
+        c = eng.cfg
+        M = args.batch * c["K"]
+        # algorithmic K-extent of the candidate segments (one-hot rank = 0 flops; the a_emb_other
+        # segment is consumed in its re-associated form softmax(a) . (E . W^T): A columns instead of da)
+        p_cols = 2 * c["dv"] + 1 + c["dz"] + c["A"]
+        flops_main = 2.0 * M * c["H"] * p_cols
+        names = {"MAIN": "seg_gemm NT 96x128 (linear_1 candidate segments, fwd)",
+                 "DW1C": "seg_gemm TN 128x128 (linear_1 candidate-column weight grad + dGt, incl. split-K reduce)"}
+        per = {k: sum(v) / len(v) for k, v in prof.items() if v}
+        dom = max(per, key=per.get) if per else None
+        roof = None
+        if dom:
+            ach = flops_main / (per[dom] * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel=names[dom], achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS,
+                        unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                        launch_ms=round(per[dom], 4), algorithmic_gflop_per_launch=round(flops_main / 1e9, 3),
+                        other={k: dict(launch_ms=round(v, 4), tflops=round(flops_main / (v * 1e-3) / 1e12, 2),
+                                       plan=_lib.plan_query(eng._dims(pool[0][0], True, 1.0 / gb), k)) for k, v in per.items()})
+        out = dict(metric="VQA-CX triplets/sec (24 candidates each), NeuralCX training step",
+                   value=round(gb * args.steps / dt, 1), unit="triplets/s", n_gpus=world, steps=args.steps,
+                   warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True,
+                   scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload="configs[1]: NeuralCX MLP train step (fwd+listwise loss/recall+bwd+Adam), synthetic "
+                                        "2048-d feats, %d candidates, batch %d per GPU, H=%d, L=%d, dropout 0.25, fp32"
+                                        % (c["K"], args.batch, c["H"], c["L"]),
+                               global_batch=gb, candidates=c["K"], dim_h=c["H"], n_layers=c["L"],
+                               parallelism="dp%d" % world, feature_table_rows=args.n_img, final_loss=round(loss, 5)),
+                   roofline=roof)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

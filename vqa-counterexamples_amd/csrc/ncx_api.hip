@@ -226,15 +226,33 @@ __global__ __launch_bounds__(256) void k_slab_reduce(const ReduceArgs a) {
 }
 
 // dst[aid[b]][:] += src[b][:], deterministically: the first occurrence of an id owns the row and adds
-// every duplicate in batch order (cx.py:280 backward: embedding scatter-add).
+// every duplicate in batch order (cx.py:280 backward: embedding scatter-add).  Ownership test and the
+// duplicate set (a bitmap in LDS, order-free to build, scanned in increasing order) are block-parallel.
+constexpr int NCX_SCATTER_MAX_B = 32768;
 __global__ __launch_bounds__(256) void k_scatter_rows_dedup(const float* __restrict__ src, const int* __restrict__ aid,
                                                             int B, int W, float* __restrict__ dst) {
+    __shared__ unsigned bits[NCX_SCATTER_MAX_B / 32];
     const int b = blockIdx.x;
     const int id = aid[b];
-    for (int j = 0; j < b; ++j) if (aid[j] == id) return;      // not the owner (uniform per block)
+    int earlier = 0;
+    for (int j = threadIdx.x; j < b; j += 256) earlier |= aid[j] == id;
+    if (__syncthreads_or(earlier)) return;                       // not the owner (uniform per block)
+    const int nw = (B + 31) / 32;
+    for (int w = threadIdx.x; w < nw; w += 256) bits[w] = 0u;
+    __syncthreads();
+    for (int j = b + threadIdx.x; j < B; j += 256)
+        if (aid[j] == id) atomicOr(&bits[j >> 5], 1u << (j & 31));
+    __syncthreads();
     for (int c = threadIdx.x; c < W; c += 256) {
         float s = dst[(long long)id * W + c];
-        for (int j = b; j < B; ++j) if (aid[j] == id) s += src[(long long)j * W + c];
+        for (int w = b >> 5; w < nw; ++w) {
+            unsigned m = bits[w];
+            while (m) {
+                const int j = (w << 5) + __ffs(m) - 1;
+                m &= m - 1;
+                s += src[(long long)j * W + c];
+            }
+        }
         dst[(long long)id * W + c] = s;
     }
 }
@@ -369,7 +387,8 @@ static int check_dims(const ncx_dims* d) {
     if (d->B < 1 || d->K < 1 || d->K > 64 || d->dv < 1 || d->dq < 1 || d->dz < 1 || d->da < 1 || d->A < 1 ||
         d->H < 1 || d->L < 1 || d->L > 3 || d->n_img < 1)
         return NCX_E_DIMS;
-    if ((long long)d->B * d->K > (1ll << 30) / 4) return NCX_E_DIMS;
+    if ((long long)d->B * d->K > (1ll << 30) / 4 || d->B > NCX_SCATTER_MAX_B) return NCX_E_DIMS;
+    if (d->dv < 4 || d->dq < 4 || d->dz < 4 || d->da < 4 || d->A < 4 || d->H < 4 || d->K < 3) return NCX_E_DIMS;   // 16-byte windows
     if (d->drop_p < 0.f || d->drop_p >= 1.f) return NCX_E_DIMS;
     return NCX_OK;
 }
@@ -378,8 +397,8 @@ static int check_dims(const ncx_dims* d) {
 // Opt-in diagnostics (ncx_profile_begin/_end): HIP events around every launch of ONE chosen GEMM, on the
 // stream it is launched on.  Off by default; the only process-global state of the library.
 // -------------------------------------------------------------------------------------------------
-struct ProfState { bool on; int id, n, cap; hipEvent_t* ev; };
-static ProfState g_prof = {false, -1, 0, 0, nullptr};
+struct ProfState { bool on; unsigned mask; int n, cap; hipEvent_t* ev; int* ids; };
+static ProfState g_prof = {false, 0u, 0, 0, nullptr, nullptr};
 
 static int run_gemm_impl(GemmArgs& a, int form, const GemmPlan& pl, float* slab, size_t slab_bytes,
                          const float* reduce_bias, hipStream_t s);
@@ -387,10 +406,10 @@ static int run_gemm_impl(GemmArgs& a, int form, const GemmPlan& pl, float* slab,
 // GEMM driver: runs `a` with plan `pl`; when split, redirects the outputs to slabs and reduces them.
 static int run_gemm(int use_id, GemmArgs& a, int form, const GemmPlan& pl, float* slab, size_t slab_bytes,
                     const float* reduce_bias, hipStream_t s) {
-    const bool rec = g_prof.on && g_prof.id == use_id && g_prof.n < g_prof.cap;
+    const bool rec = g_prof.on && ((g_prof.mask >> use_id) & 1u) && g_prof.n < g_prof.cap;
     if (rec) NCX_HIP_TRY(hipEventRecord(g_prof.ev[2 * g_prof.n], s));
     const int rc = run_gemm_impl(a, form, pl, slab, slab_bytes, reduce_bias, s);
-    if (rec) { NCX_HIP_TRY(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s)); ++g_prof.n; }
+    if (rec) { NCX_HIP_TRY(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s)); g_prof.ids[g_prof.n] = use_id; ++g_prof.n; }
     return rc;
 }
 
@@ -718,28 +737,29 @@ int ncx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 }
 
 // ---- diagnostics ---------------------------------------------------------------------------------------
-int ncx_profile_begin(int32_t gemm_id, int32_t max_launches) {
-    if (g_prof.on || gemm_id < 0 || gemm_id >= U_COUNT || max_launches < 1 || max_launches > 4096) return NCX_E_DIMS;
+int ncx_profile_begin(uint32_t gemm_mask, int32_t max_launches) {
+    if (g_prof.on || gemm_mask == 0 || (gemm_mask >> U_COUNT) != 0 || max_launches < 1 || max_launches > 65536) return NCX_E_DIMS;
     g_prof.ev = (hipEvent_t*)malloc(sizeof(hipEvent_t) * 2 * (size_t)max_launches);
-    if (!g_prof.ev) return NCX_E_NULL;
+    g_prof.ids = (int*)malloc(sizeof(int) * (size_t)max_launches);
+    if (!g_prof.ev || !g_prof.ids) return NCX_E_NULL;
     for (int i = 0; i < 2 * max_launches; ++i) NCX_HIP_TRY(hipEventCreate(&g_prof.ev[i]));
-    g_prof.id = gemm_id; g_prof.n = 0; g_prof.cap = max_launches; g_prof.on = true;
+    g_prof.mask = gemm_mask; g_prof.n = 0; g_prof.cap = max_launches; g_prof.on = true;
     return NCX_OK;
 }
 
-int ncx_profile_end(float* ms, int32_t cap) {
+int ncx_profile_end(float* ms, int32_t* ids, int32_t cap) {
     if (!g_prof.on) return NCX_E_FLAGS;
     int n = 0;
     for (int i = 0; i < g_prof.n; ++i) {
         if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess) break;
         float t = 0.f;
         if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) break;
-        if (ms && n < cap) ms[n] = t;
+        if (n < cap) { if (ms) ms[n] = t; if (ids) ids[n] = g_prof.ids[i]; }
         ++n;
     }
     for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
-    free(g_prof.ev);
-    g_prof.ev = nullptr; g_prof.on = false; g_prof.id = -1; g_prof.n = 0; g_prof.cap = 0;
+    free(g_prof.ev); free(g_prof.ids);
+    g_prof.ev = nullptr; g_prof.ids = nullptr; g_prof.on = false; g_prof.mask = 0; g_prof.n = 0; g_prof.cap = 0;
     return n < cap ? n : cap;
 }
 

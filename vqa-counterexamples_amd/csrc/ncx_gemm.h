@@ -97,76 +97,172 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __host__ __device__ constexpr int pitch_rowk(int c) { return ((c - 16 + 31) / 32) * 32 + 16; }  // >= c, = 16 mod 32
 
-struct RowMeta {
-    const float* p0;
-    const float* p1;
-    float mx, inv;
-};
-
-__device__ __forceinline__ RowMeta fetch_meta(const XDesc& d, int r) {
-    RowMeta m; m.p0 = nullptr; m.p1 = nullptr; m.mx = 0.f; m.inv = 0.f;
-    if (r < d.rows) {
-        switch (d.kind) {
-        case X_PLAIN:      m.p0 = d.base + (long long)r * d.ld; break;
-        case X_GATHER:     m.p0 = d.base + (long long)d.idx[r] * d.ld; break;
-        case X_GATHER_MUL: m.p0 = d.base + (long long)d.idx[r] * d.ld;
-                           m.p1 = d.base + (long long)d.idx2[r] * d.ld; break;
-        default:           m.p0 = d.base + (long long)r * d.ld; m.mx = d.mx[r]; m.inv = d.inv[r]; break;
-        }
-    }
-    return m;
+// 4 consecutive columns of one row (always a valid row pointer; cols >= 4).  The load is UNCONDITIONAL and
+// identical for interior and edge tiles: the 16-byte window is slid left to stay inside [0, cols)
+// (a per-lane guard around a load makes hipcc put every load in its own basic block, and two alternative
+// load paths merge through register copies that force an early s_waitcnt).  Edge tiles repair the window
+// afterwards with fix_window (pure VALU, at LDS-store time).
+__device__ __forceinline__ f32x4 load_window(const float* p, int c, int cols) {
+    return *(const f32x4u*)(p + min(c, cols - 4));
 }
-
-// 4 consecutive columns c..c+3 of one row, zero beyond `cols` / for an invalid row.
+// w = load_window(p, c, cols)  ->  {x[c], x[c+1], x[c+2], x[c+3]} with zeros at and beyond cols
+__device__ __forceinline__ f32x4 fix_window(f32x4 w, int c, int cols) {
+    const int sh = c - min(c, cols - 4);          // 0 for interior windows
+    f32x4 r;
+    r[0] = sh == 0 ? w[0] : sh == 1 ? w[1] : sh == 2 ? w[2] : w[3];
+    r[1] = sh == 0 ? w[1] : sh == 1 ? w[2] : w[3];
+    r[2] = sh == 0 ? w[2] : w[3];
+    r[3] = w[3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = (c + j < cols) ? r[j] : 0.f;
+    return r;
+}
+// guarded form used by the bandwidth kernels (zero fill, any cols >= 1)
 __device__ __forceinline__ f32x4 load4(const float* p, int c, int cols) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (p != nullptr) {
-        if (c + 3 < cols) {
-            v = *(const f32x4u*)(p + c);
-        } else {
-            if (c     < cols) v[0] = p[c];
-            if (c + 1 < cols) v[1] = p[c + 1];
-            if (c + 2 < cols) v[2] = p[c + 2];
-        }
+    if (c + 3 < cols) {
+        v = *(const f32x4u*)(p + c);
+    } else {
+        if (c     < cols) v[0] = p[c];
+        if (c + 1 < cols) v[1] = p[c + 1];
+        if (c + 2 < cols) v[2] = p[c + 2];
     }
     return v;
 }
 
-__device__ __forceinline__ f32x4 xform(int kind, const RowMeta& m, f32x4 v0, f32x4 v1, int c, int cols) {
-    if (kind == X_GATHER_MUL) {
-        return v0 * v1;
-    } else if (kind == X_SOFTMAX) {
-        f32x4 r;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            r[j] = (m.p0 != nullptr && c + j < cols) ? __expf(v0[j] - m.mx) * m.inv : 0.f;
-        return r;
-    }
-    return v0;
-}
+// Per-thread loader of one operand tile.
+//   COLK  (col-is-k): tile [EXT rows][32 k-cols]; thread owns column quad 4*(tid&7) of rows (tid>>3) + 32*i
+//   !COLK (row-is-k): tile [32 k-rows][EXT cols]; thread owns row (tid>>3), column quads 4*(tid&7) + 32*i
+// i < NV = EXT/32 either way, so a wave-instruction always covers 8 rows x 128 contiguous bytes.
+template <bool COLK, int EXT>
+struct OpLoader {
+    static constexpr int NV = EXT / 32;
+    static constexpr int NR = COLK ? NV : 1;             // distinct rows per thread
+    static constexpr int PITCH = COLK ? GEMM_BK + 2 : pitch_rowk(EXT);
+    static constexpr int ELEMS = (COLK ? EXT : GEMM_BK) * PITCH;
+    static_assert(EXT % 32 == 0, "tile extent");
 
-// Thread <-> element mapping of a tile with R rows x C cols (C in {32, 64, 128}); 256 threads.
-template <int R, int C>
-struct TileMap {
-    static constexpr int TPR = C / 4;          // threads per row
-    static constexpr int RP  = 256 / TPR;      // rows per pass
-    static constexpr int NP  = (R + RP - 1) / RP;
-    static_assert(256 % TPR == 0, "tile width");
-    static_assert(R % RP == 0, "tile rows");
+    f32x4 v0[NV], v1[NV];
+    const float* p0[NR];
+    const float* p1[NR];
+    float mx[NR], inv[NR];
+    unsigned rowmask;            // bit i: row i of this thread is inside the matrix
+    int kind, cols, rows, o0;    // o0: first row (COLK) / first column (!COLK) of the tile in x-space
+    int nidx0, nidx1;            // !COLK: gather indices prefetched for the NEXT k-step
+    bool full_o;                 // !COLK: the tile's column range is fully inside the matrix
+    bool full_k;                 // COLK: set per k-step
+
+    __device__ __forceinline__ void setup(const XDesc& d, int origin, int tid) {
+        kind = d.kind; cols = d.cols; rows = d.rows; o0 = origin;
+        full_o = origin + EXT <= d.cols;
+        if (COLK) {
+            rowmask = 0;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int r = origin + i * 32 + (tid >> 3);
+                const int rc = min(r, d.rows - 1);
+                rowmask |= (r < d.rows ? 1u : 0u) << i;
+                if (kind == X_GATHER) {
+                    p0[i] = d.base + (long long)d.idx[rc] * d.ld;
+                } else if (kind == X_GATHER_MUL) {
+                    p0[i] = d.base + (long long)d.idx[rc] * d.ld;
+                    p1[i] = d.base + (long long)d.idx2[rc] * d.ld;
+                } else {
+                    p0[i] = d.base + (long long)rc * d.ld;
+                    if (kind == X_SOFTMAX) { mx[i] = d.mx[rc]; inv[i] = d.inv[rc]; }
+                }
+            }
+        }
+    }
+    // !COLK: fetch the gather indices of k-row block `k` (consumed by the following issue()).
+    __device__ __forceinline__ void prefetch_rows(const XDesc& d, int k, int tid) {
+        if (!COLK) {
+            const int rc = min(k + (tid >> 3), d.rows - 1);
+            if (kind == X_GATHER || kind == X_GATHER_MUL) nidx0 = d.idx[rc];
+            if (kind == X_GATHER_MUL) nidx1 = d.idx2[rc];
+        }
+    }
+    __device__ __forceinline__ void issue(const XDesc& d, int k, int tid) {
+        int c0, cstride;
+        if (COLK) {
+            c0 = k + 4 * (tid & 7); cstride = 0;
+            full_k = k + GEMM_BK <= cols;
+        } else {
+            const int r = k + (tid >> 3);
+            const int rc = min(r, rows - 1);
+            rowmask = r < rows ? 1u : 0u;
+            if (kind == X_GATHER) {
+                p0[0] = d.base + (long long)nidx0 * d.ld;
+            } else if (kind == X_GATHER_MUL) {
+                p0[0] = d.base + (long long)nidx0 * d.ld;
+                p1[0] = d.base + (long long)nidx1 * d.ld;
+            } else {
+                p0[0] = d.base + (long long)rc * d.ld;
+                if (kind == X_SOFTMAX) { mx[0] = d.mx[rc]; inv[0] = d.inv[rc]; }
+            }
+            c0 = o0 + 4 * (tid & 7); cstride = 32;
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v0[i] = load_window(p0[COLK ? i : 0], c0 + cstride * i, cols);
+        if (kind == X_GATHER_MUL) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v1[i] = load_window(p1[COLK ? i : 0], c0 + cstride * i, cols);
+        }
+    }
+
+    template <int KIND, bool FULL>
+    __device__ __forceinline__ void store_t(float* lds, int k, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int ri = COLK ? i : 0;
+            f32x4 v = v0[i];
+            if (KIND == X_GATHER_MUL) {
+                v = v * v1[i];
+            } else if (KIND == X_SOFTMAX) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = __expf(v[j] - mx[ri]) * inv[ri];
+            }
+            if (!FULL) {
+                const int c = COLK ? k + 4 * (tid & 7) : o0 + 4 * (tid & 7) + 32 * i;
+                v = fix_window(v, c, cols);
+            }
+            const bool rv = (rowmask >> ri) & 1u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = rv ? v[j] : 0.f;
+            if (COLK) {
+                float* dst = lds + (i * 32 + (tid >> 3)) * PITCH + 4 * (tid & 7);
+                *(f32x2*)dst = f32x2{v[0], v[1]};
+                *(f32x2*)(dst + 2) = f32x2{v[2], v[3]};
+            } else {
+                float* dst = lds + (tid >> 3) * PITCH + 4 * (tid & 7) + 32 * i;
+                *(f32x4*)dst = v;
+            }
+        }
+    }
+    // transform + zero padding + write into the LDS tile; k = k position the registers were issued for
+    __device__ __forceinline__ void store(float* lds, int k, int tid) const {
+        const bool full = COLK ? full_k : full_o;
+        if (full) {
+            if (kind == X_GATHER_MUL) store_t<X_GATHER_MUL, true>(lds, k, tid);
+            else if (kind == X_SOFTMAX) store_t<X_SOFTMAX, true>(lds, k, tid);
+            else store_t<X_PLAIN, true>(lds, k, tid);
+        } else {
+            if (kind == X_GATHER_MUL) store_t<X_GATHER_MUL, false>(lds, k, tid);
+            else if (kind == X_SOFTMAX) store_t<X_SOFTMAX, false>(lds, k, tid);
+            else store_t<X_PLAIN, false>(lds, k, tid);
+        }
+    }
 };
 
 template <int BM, int BN, bool A_COLK, bool B_COLK>
 struct GemmCfg {
     static constexpr int BK = GEMM_BK;
-    static constexpr int AR = A_COLK ? BM : BK, AC = A_COLK ? BK : BM;   // A tile rows/cols in x-space
-    static constexpr int BR = B_COLK ? BN : BK, BC = B_COLK ? BK : BN;
-    static constexpr int PA = A_COLK ? BK + 2 : pitch_rowk(BM);
-    static constexpr int PB = B_COLK ? BK + 2 : pitch_rowk(BN);
-    static constexpr int A_ELEMS = AR * PA, B_ELEMS = BR * PB;
+    typedef OpLoader<A_COLK, BM> ALoad;
+    typedef OpLoader<B_COLK, BN> BLoad;
+    static constexpr int PA = ALoad::PITCH, PB = BLoad::PITCH;
+    static constexpr int A_ELEMS = ALoad::ELEMS, B_ELEMS = BLoad::ELEMS;
     static constexpr int LDS_BYTES = 2 * (A_ELEMS + B_ELEMS) * 4;
     static constexpr int WM = BM / 32, WN = BN / 32;   // 16x16 blocks per wave (2x2 waves)
-    typedef TileMap<AR, AC> AMap;
-    typedef TileMap<BR, BC> BMap;
 };
 
 __device__ __forceinline__ float apply_epilogue(const EpiArgs& e, float v, int r, int n, int ncols_total) {
@@ -186,8 +282,6 @@ __device__ __forceinline__ float apply_epilogue(const EpiArgs& e, float v, int r
 template <int BM, int BN, bool A_COLK, bool B_COLK>
 __global__ __launch_bounds__(256, 2) void seg_gemm_kernel(const GemmArgs args) {
     typedef GemmCfg<BM, BN, A_COLK, B_COLK> Cfg;
-    typedef typename Cfg::AMap AMap;
-    typedef typename Cfg::BMap BMap;
     constexpr int BK = Cfg::BK, PA = Cfg::PA, PB = Cfg::PB, WM = Cfg::WM, WN = Cfg::WN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const lds_a = smem;                               // [2][A_ELEMS]
@@ -229,73 +323,9 @@ __global__ __launch_bounds__(256, 2) void seg_gemm_kernel(const GemmArgs args) {
         }
     }
 
-    // ---- per-thread tile coordinates ------------------------------------------------------------
-    const int a_tr = tid / AMap::TPR, a_tc = (tid % AMap::TPR) * 4;   // row-in-pass, col offset
-    const int b_tr = tid / BMap::TPR, b_tc = (tid % BMap::TPR) * 4;
-
-    RowMeta a_meta[AMap::NP], b_meta[BMap::NP];
-    f32x4 a_v0[AMap::NP], a_v1[AMap::NP], b_v0[BMap::NP], b_v1[BMap::NP];
-    int a_kind = 0, b_kind = 0, a_cols = 0, b_cols = 0;
-
-    auto load_seg_meta = [&](int s) {
-        const XDesc& da = args.a[args.mode == MODE_GROUP ? 0 : s];
-        const XDesc& db = args.b[s];
-        a_kind = da.kind; b_kind = db.kind; a_cols = da.cols; b_cols = db.cols;
-        if (A_COLK) {
-#pragma unroll
-            for (int p = 0; p < AMap::NP; ++p) a_meta[p] = fetch_meta(da, m0 + p * AMap::RP + a_tr);
-        }
-        if (B_COLK) {
-#pragma unroll
-            for (int p = 0; p < BMap::NP; ++p) b_meta[p] = fetch_meta(db, n0 + p * BMap::RP + b_tr);
-        }
-    };
-
-    auto issue_loads = [&](int s, int k) {
-        const XDesc& da = args.a[args.mode == MODE_GROUP ? 0 : s];
-        const XDesc& db = args.b[s];
-        if (!A_COLK) {
-#pragma unroll
-            for (int p = 0; p < AMap::NP; ++p) a_meta[p] = fetch_meta(da, k + p * AMap::RP + a_tr);
-        }
-        if (!B_COLK) {
-#pragma unroll
-            for (int p = 0; p < BMap::NP; ++p) b_meta[p] = fetch_meta(db, k + p * BMap::RP + b_tr);
-        }
-        const int ac = A_COLK ? k + a_tc : m0 + a_tc;
-        const int bc = B_COLK ? k + b_tc : n0 + b_tc;
-#pragma unroll
-        for (int p = 0; p < AMap::NP; ++p) {
-            a_v0[p] = load4(a_meta[p].p0, ac, a_cols);
-            if (a_kind == X_GATHER_MUL) a_v1[p] = load4(a_meta[p].p1, ac, a_cols);
-        }
-#pragma unroll
-        for (int p = 0; p < BMap::NP; ++p) {
-            b_v0[p] = load4(b_meta[p].p0, bc, b_cols);
-            if (b_kind == X_GATHER_MUL) b_v1[p] = load4(b_meta[p].p1, bc, b_cols);
-        }
-    };
-
-    auto store_lds = [&](int buf, int k) {
-        float* la = lds_a + buf * Cfg::A_ELEMS;
-        float* lb = lds_b + buf * Cfg::B_ELEMS;
-        const int ac = A_COLK ? k + a_tc : m0 + a_tc;
-        const int bc = B_COLK ? k + b_tc : n0 + b_tc;
-#pragma unroll
-        for (int p = 0; p < AMap::NP; ++p) {
-            const f32x4 v = xform(a_kind, a_meta[p], a_v0[p], a_v1[p], ac, a_cols);
-            float* dst = la + (p * AMap::RP + a_tr) * PA + a_tc;
-            if (A_COLK) { *(f32x2*)dst = f32x2{v[0], v[1]}; *(f32x2*)(dst + 2) = f32x2{v[2], v[3]}; }
-            else        { *(f32x4*)dst = v; }
-        }
-#pragma unroll
-        for (int p = 0; p < BMap::NP; ++p) {
-            const f32x4 v = xform(b_kind, b_meta[p], b_v0[p], b_v1[p], bc, b_cols);
-            float* dst = lb + (p * BMap::RP + b_tr) * PB + b_tc;
-            if (B_COLK) { *(f32x2*)dst = f32x2{v[0], v[1]}; *(f32x2*)(dst + 2) = f32x2{v[2], v[3]}; }
-            else        { *(f32x4*)dst = v; }
-        }
-    };
+    typename Cfg::ALoad la;
+    typename Cfg::BLoad lb;
+    auto adesc = [&](int s) -> const XDesc& { return args.a[args.mode == MODE_GROUP ? 0 : s]; };
 
     f32x4 acc[WM][WN];
 #pragma unroll
@@ -304,18 +334,18 @@ __global__ __launch_bounds__(256, 2) void seg_gemm_kernel(const GemmArgs args) {
         for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int buf) {
-        const float* la = lds_a + buf * Cfg::A_ELEMS;
-        const float* lb = lds_b + buf * Cfg::B_ELEMS;
+        const float* pa = lds_a + buf * Cfg::A_ELEMS;
+        const float* pb = lds_b + buf * Cfg::B_ELEMS;
 #pragma unroll
         for (int k4 = 0; k4 < BK / 4; ++k4) {
             float af[WM], bf[WN];
             const int kk = k4 * 4 + lk;
 #pragma unroll
             for (int i = 0; i < WM; ++i)
-                af[i] = A_COLK ? la[(wm0 + i * 16 + li) * PA + kk] : la[kk * PA + wm0 + i * 16 + li];
+                af[i] = A_COLK ? pa[(wm0 + i * 16 + li) * PA + kk] : pa[kk * PA + wm0 + i * 16 + li];
 #pragma unroll
             for (int j = 0; j < WN; ++j)
-                bf[j] = B_COLK ? lb[(wn0 + j * 16 + li) * PB + kk] : lb[kk * PB + wn0 + j * 16 + li];
+                bf[j] = B_COLK ? pb[(wn0 + j * 16 + li) * PB + kk] : pb[kk * PB + wn0 + j * 16 + li];
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -326,20 +356,39 @@ __global__ __launch_bounds__(256, 2) void seg_gemm_kernel(const GemmArgs args) {
 
     // ---- main loop ------------------------------------------------------------------------------
     if (step_begin < step_end) {
-        load_seg_meta(seg);
-        issue_loads(seg, kpos);
-        store_lds(0, kpos);
+        la.setup(adesc(seg), A_COLK ? m0 : m0, tid);
+        lb.setup(args.b[seg], B_COLK ? n0 : n0, tid);
+        la.prefetch_rows(adesc(seg), kpos, tid);
+        lb.prefetch_rows(args.b[seg], kpos, tid);
+        la.issue(adesc(seg), kpos, tid);
+        lb.issue(args.b[seg], kpos, tid);
+        la.prefetch_rows(adesc(seg), kpos + BK, tid);
+        lb.prefetch_rows(args.b[seg], kpos + BK, tid);
+        la.store(lds_a, kpos, tid);
+        lb.store(lds_b, kpos, tid);
         __syncthreads();
         int buf = 0;
         for (int step = step_begin; step < step_end; ++step) {
             const bool has_next = step + 1 < step_end;
             int nkpos = kpos + BK, nseg = seg;
             if (has_next) {
-                if (nkpos >= args.klen[seg]) { nseg = seg + 1; nkpos = 0; load_seg_meta(nseg); }
-                issue_loads(nseg, nkpos);
+                if (nkpos >= args.klen[seg]) {
+                    nseg = seg + 1; nkpos = 0;
+                    la.setup(adesc(nseg), m0, tid);
+                    lb.setup(args.b[nseg], n0, tid);
+                    la.prefetch_rows(adesc(nseg), 0, tid);
+                    lb.prefetch_rows(args.b[nseg], 0, tid);
+                }
+                la.issue(adesc(nseg), nkpos, tid);
+                lb.issue(args.b[nseg], nkpos, tid);
+                la.prefetch_rows(adesc(nseg), nkpos + BK, tid);
+                lb.prefetch_rows(args.b[nseg], nkpos + BK, tid);
             }
             compute(buf);
-            if (has_next) store_lds(buf ^ 1, nkpos);
+            if (has_next) {
+                la.store(lds_a + (buf ^ 1) * Cfg::A_ELEMS, nkpos, tid);
+                lb.store(lds_b + (buf ^ 1) * Cfg::B_ELEMS, nkpos, tid);
+            }
             __syncthreads();
             buf ^= 1; seg = nseg; kpos = nkpos;
         }

@@ -78,9 +78,9 @@ def lib():
     L.ncx_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float,
                                 C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]
     L.ncx_profile_begin.restype = C.c_int
-    L.ncx_profile_begin.argtypes = [C.c_int32, C.c_int32]
+    L.ncx_profile_begin.argtypes = [C.c_uint32, C.c_int32]
     L.ncx_profile_end.restype = C.c_int
-    L.ncx_profile_end.argtypes = [C.POINTER(C.c_float), C.c_int32]
+    L.ncx_profile_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int32]
     L.ncx_plan_query.restype = C.c_int
     L.ncx_plan_query.argtypes = [C.POINTER(NcxDims), C.c_int32, C.POINTER(C.c_int32)]
     _lib = L
@@ -97,3 +97,34 @@ def check(rc, what):
 
 def version():
     return lib().ncx_version().decode()
+
+
+GEMM_IDS = dict(GT=0, SH=1, MAIN=2, FWD_L=3, DW1C=4, DW1S=5, DE=6, DW1AK=7, DAGT=8, DWL=9, DXL=10)
+
+
+def profile_begin(names, max_launches=4096):
+    mask = 0
+    for n in names:
+        mask |= 1 << GEMM_IDS[n]
+    check(lib().ncx_profile_begin(mask, max_launches), "ncx_profile_begin")
+
+
+def profile_end(cap=4096):
+    """-> {gemm name: [ms, ...]} (synchronises the recorded events)."""
+    ms = (C.c_float * cap)()
+    ids = (C.c_int32 * cap)()
+    n = lib().ncx_profile_end(ms, ids, cap)
+    if n < 0:
+        check(n, "ncx_profile_end")
+    inv = {v: k for k, v in GEMM_IDS.items()}
+    out = {}
+    for i in range(n):
+        out.setdefault(inv[ids[i]], []).append(float(ms[i]))
+    return out
+
+
+def plan_query(d, name):
+    out = (C.c_int32 * 6)()
+    check(lib().ncx_plan_query(C.byref(d), GEMM_IDS[name], out), "ncx_plan_query")
+    return dict(form=("NT", "TN", "NN")[out[0]], M=out[1], N=out[2], ksteps=out[3],
+                tile=("64x64", "128x128", "96x128")[out[4]], ksplit=out[5])

@@ -1,0 +1,130 @@
+"""Training / evaluation engine of the NeuralCX hot path on one MI355X per process.
+
+Replaces the inner body of the reference's train loop (counterexamples.py:322-339) and of eval_model
+(counterexamples.py:460-468): forward, listwise loss + recall, backward, Adam -- all HIP kernels behind the
+C ABI.  Data parallelism (net-new; the reference is single-GPU): one process per GPU, every
+rank scales its loss by 1/B_global so a plain SUM all-reduce of the flat gradient buffer over RCCL
+reproduces the single-GPU gradient of the global batch; parameters stay replicated.
+
+Memory layout in HBM: all trainable tensors live back to back in ONE flat fp32 buffer (answer_embedding,
+linear_1.weight [H, 14089], biases, out), gradients and the two Adam moments mirror it, so the optimizer
+is one fused launch and the gradient exchange is one (bucketed) collective.
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from ._lib import NCX_F_ALL
+
+STATE_NAMES = ("answer_embedding.weight", "linear_1.weight", "linear_1.bias", "linear_2.weight", "linear_2.bias",
+               "linear_3.weight", "linear_3.bias", "out.weight", "out.bias")
+
+
+def param_shapes(K, dv, dq, dz, da, A, H, L):
+    din = 3 * dv + 2 * da + 2 * dz + dq + K + 1          # cx.py:245-251
+    s = {"answer_embedding.weight": (A, da), "linear_1.weight": (H, din), "linear_1.bias": (H,)}
+    if L >= 2: s["linear_2.weight"] = (H, H); s["linear_2.bias"] = (H,)
+    if L >= 3: s["linear_3.weight"] = (H, H); s["linear_3.bias"] = (H,)
+    s["out.weight"] = (1, H); s["out.bias"] = (1,)
+    return s
+
+
+class FlatParams:
+    """One flat buffer + named views (state_dict names of the reference, cx.py:240-257)."""
+
+    def __init__(self, shapes: Dict[str, tuple], device):
+        self.shapes = shapes
+        self.offsets, off = {}, 0
+        for n, shp in shapes.items():
+            self.offsets[n] = off
+            off += (math.prod(shp) + 3) // 4 * 4          # keep every tensor 16-byte aligned
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=device)
+        self.views = {n: self.flat[o:o + math.prod(shapes[n])].view(shapes[n]) for n, o in self.offsets.items()}
+
+    def like(self):
+        other = FlatParams.__new__(FlatParams)
+        other.shapes, other.offsets, other.numel = self.shapes, self.offsets, self.numel
+        other.flat = torch.zeros_like(self.flat)
+        other.views = {n: other.flat[o:o + math.prod(self.shapes[n])].view(self.shapes[n]) for n, o in self.offsets.items()}
+        return other
+
+    def fields(self):
+        return {ops.STATE_TO_FIELD[n]: v for n, v in self.views.items()}
+
+
+class NeuralCXEngine:
+    def __init__(self, K=24, dv=2048, dq=2400, dz=360, da=2400, A=2000, H=256, L=1, drop_p=0.25, lr=1e-4,
+                 device="cuda:0", spec: Optional[dict] = None, world_size=1, process_group=None):
+        self.cfg = dict(K=K, dv=dv, dq=dq, dz=dz, da=da, A=A, H=H, L=L)
+        self.drop_p, self.lr = drop_p, lr
+        self.device = torch.device(device)
+        self.flags = ops.flags_from_spec(spec) if spec is not None else NCX_F_ALL
+        self.params = FlatParams(param_shapes(**self.cfg), self.device)
+        self.grads = self.params.like()
+        self.exp_avg = torch.zeros_like(self.params.flat)
+        self.exp_avg_sq = torch.zeros_like(self.params.flat)
+        self.step_count = 0
+        self.world_size, self.pg = world_size, process_group
+        self._ws = None
+        self._ws_key = None
+        self.seed = 42
+
+    # ---- parameters --------------------------------------------------------------------------------------
+    def init_parameters(self, seed=42, emb=None):
+        """torch default init distributions: Embedding N(0,1), Linear U(+-1/sqrt(fan_in)) (cx.py:240-257)."""
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        for n, v in self.params.views.items():
+            if n == "answer_embedding.weight":
+                t = torch.randn(v.shape, generator=g) if emb is None else torch.as_tensor(emb, dtype=torch.float32)
+            else:
+                fan_in = v.shape[1] if v.dim() == 2 else self.params.shapes[n.replace("bias", "weight")][1]
+                b = 1.0 / math.sqrt(fan_in)
+                t = (torch.rand(v.shape, generator=g) * 2 - 1) * b
+            v.copy_(t)
+
+    def load_state(self, state: Dict[str, torch.Tensor]):
+        for n, v in self.params.views.items():
+            v.copy_(state[n].to(self.device))
+
+    def state_dict(self):
+        return {n: v.detach().clone() for n, v in self.params.views.items()}
+
+    # ---- steps -------------------------------------------------------------------------------------------
+    def _dims(self, batch: ops.Batch, training: bool, loss_scale: float):
+        c = self.cfg
+        d = ops.make_dims(batch, H=c["H"], L=c["L"], da=c["da"], A=c["A"], flags=self.flags, training=training,
+                          drop_p=self.drop_p if training else 0.0, loss_scale=loss_scale,
+                          seed=(self.seed << 32) ^ self.step_count)
+        key = (d.B, d.K, d.n_img >= 0)
+        need = ops.workspace_bytes(d) + 256
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return d
+
+    def forward(self, batch: ops.Batch, training=False):
+        d = self._dims(batch, training, 0.0)
+        return ops.forward(d, batch, self.params.fields(), self._ws), d
+
+    def eval_step(self, batch: ops.Batch, gt: torch.Tensor):
+        scores, _ = self.forward(batch, training=False)
+        r = ops.ranking_loss(scores, gt, want_grad=False)
+        r["scores"] = scores
+        return r
+
+    def train_step(self, batch: ops.Batch, gt: torch.Tensor, global_batch: Optional[int] = None):
+        """forward + loss + backward + (all-reduce) + Adam.  Returns device tensors; never syncs the host."""
+        B = batch.img_idx.shape[0]
+        gb = global_batch if global_batch is not None else B * self.world_size
+        self.step_count += 1
+        d = self._dims(batch, True, 1.0 / gb)
+        scores = ops.forward(d, batch, self.params.fields(), self._ws)
+        r = ops.ranking_loss(scores, gt, scale=1.0 / gb)
+        ops.backward(d, batch, self.params.fields(), self._ws, r["dscores"], self.grads.fields())
+        if self.world_size > 1:
+            torch.distributed.all_reduce(self.grads.flat, group=self.pg)          # RCCL sum over xGMI
+        ops.adam_step(self.params.flat, self.grads.flat, self.exp_avg, self.exp_avg_sq, self.step_count, lr=self.lr)
+        r["scores"] = scores
+        return r
