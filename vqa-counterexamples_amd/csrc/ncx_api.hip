@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void k_prep(ncx_dims d, ncx_inputs in, int* __
             for (int j = 0; j < 4; ++j) if (c + j < d.A) s += __expf(v[j] - m);
         }
         s = wave_sum(s);
-        if (lane == 0) { mx[r] = m; inv[r] = 1.f / s; }
+        // base-2 log-sum-exp: softmax(a)[c] = exp2(a[c]*log2e - lse2)
+        if (lane == 0) { mx[r] = m * 1.44269504088896341f + __log2f(s); inv[r] = 0.f; }
     }
 }
 

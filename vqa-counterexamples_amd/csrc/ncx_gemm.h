@@ -6,7 +6,8 @@
 //   X_PLAIN       x(r,c) = base[r*ld + c]
 //   X_GATHER      x(r,c) = base[idx[r]*ld + c]                       (feature-table / embedding row gather)
 //   X_GATHER_MUL  x(r,c) = base[idx[r]*ld + c] * base[idx2[r]*ld + c] (v_orig * v_other, cx.py:296)
-//   X_SOFTMAX     x(r,c) = exp(base[r*ld + c] - mx[r]) * inv[r]      (softmax(a_knns), cx.py:281)
+//   X_SOFTMAX     x(r,c) = exp2(base[r*ld + c]*log2(e) - lse2[r])     (softmax(a_knns), cx.py:281;
+//                 lse2[r] = log2(sum_c exp(x - max)) + max*log2(e), one FMA + one v_exp_f32 per element)
 //
 // This is how the reference's torch.cat of ten segments (vqa/models/cx.py:309-320) is consumed without
 // building it: the first Linear layer is a CHAIN of (segment of X, column slice of linear_1.weight) pairs
@@ -27,6 +28,7 @@
 // issued before the MFMAs of step t and written to the other LDS buffer after them.
 #pragma once
 #include "ncx_common.h"
+#include <type_traits>
 
 namespace ncx {
 
@@ -36,8 +38,8 @@ struct XDesc {
     const float* base;
     const int*   idx;
     const int*   idx2;
-    const float* mx;
-    const float* inv;
+    const float* mx;     // X_SOFTMAX: lse2 per row
+    const float* inv;    // unused (kept for layout)
     long long    ld;
     int kind;
     int rows;
@@ -138,14 +140,14 @@ template <bool COLK, int EXT>
 struct OpLoader {
     static constexpr int NV = EXT / 32;
     static constexpr int NR = COLK ? NV : 1;             // distinct rows per thread
-    static constexpr int PITCH = COLK ? GEMM_BK + 2 : pitch_rowk(EXT);
+    static constexpr int PITCH = COLK ? GEMM_BK + 4 : pitch_rowk(EXT);
     static constexpr int ELEMS = (COLK ? EXT : GEMM_BK) * PITCH;
     static_assert(EXT % 32 == 0, "tile extent");
 
     f32x4 v0[NV], v1[NV];
     const float* p0[NR];
     const float* p1[NR];
-    float mx[NR], inv[NR];
+    float mx[NR];                // X_SOFTMAX: base-2 log-sum-exp of the row
     unsigned rowmask;            // bit i: row i of this thread is inside the matrix
     int kind, cols, rows, o0;    // o0: first row (COLK) / first column (!COLK) of the tile in x-space
     int nidx0, nidx1;            // !COLK: gather indices prefetched for the NEXT k-step
@@ -169,7 +171,7 @@ struct OpLoader {
                     p1[i] = d.base + (long long)d.idx2[rc] * d.ld;
                 } else {
                     p0[i] = d.base + (long long)rc * d.ld;
-                    if (kind == X_SOFTMAX) { mx[i] = d.mx[rc]; inv[i] = d.inv[rc]; }
+                    if (kind == X_SOFTMAX) { mx[i] = d.mx[rc]; }
                 }
             }
         }
@@ -198,7 +200,7 @@ struct OpLoader {
                 p1[0] = d.base + (long long)nidx1 * d.ld;
             } else {
                 p0[0] = d.base + (long long)rc * d.ld;
-                if (kind == X_SOFTMAX) { mx[0] = d.mx[rc]; inv[0] = d.inv[rc]; }
+                if (kind == X_SOFTMAX) { mx[0] = d.mx[rc]; }
             }
             c0 = o0 + 4 * (tid & 7); cstride = 32;
         }
@@ -220,7 +222,7 @@ struct OpLoader {
                 v = v * v1[i];
             } else if (KIND == X_SOFTMAX) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = __expf(v[j] - mx[ri]) * inv[ri];
+                for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[j], 1.44269504088896341f, -mx[ri]));
             }
             if (!FULL) {
                 const int c = COLK ? k + 4 * (tid & 7) : o0 + 4 * (tid & 7) + 32 * i;
@@ -229,16 +231,62 @@ struct OpLoader {
             const bool rv = (rowmask >> ri) & 1u;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = rv ? v[j] : 0.f;
-            if (COLK) {
-                float* dst = lds + (i * 32 + (tid >> 3)) * PITCH + 4 * (tid & 7);
-                *(f32x2*)dst = f32x2{v[0], v[1]};
-                *(f32x2*)(dst + 2) = f32x2{v[2], v[3]};
-            } else {
-                float* dst = lds + (tid >> 3) * PITCH + 4 * (tid & 7) + 32 * i;
-                *(f32x4*)dst = v;
-            }
+            float* dst = COLK ? lds + (i * 32 + (tid >> 3)) * PITCH + 4 * (tid & 7)
+                              : lds + (tid >> 3) * PITCH + 4 * (tid & 7) + 32 * i;
+            *(f32x4*)dst = v;
         }
     }
+
+    // ---- interior fast path: no bounds handling, kind compile-time, straight-line -------------------
+    // KIND: COLK operands have their row pointers resolved in setup(), so X_GATHER == X_PLAIN there.
+    template <int KIND>
+    __device__ __forceinline__ void issue_fast(const XDesc& d, int k, int tid) {
+        if (COLK) {
+            const int c = k + 4 * (tid & 7);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v0[i] = *(const f32x4u*)(p0[i] + c);
+            if (KIND == X_GATHER_MUL) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) v1[i] = *(const f32x4u*)(p1[i] + c);
+            }
+        } else {
+            const int r = k + (tid >> 3);
+            const int c = o0 + 4 * (tid & 7);
+            if (KIND == X_GATHER || KIND == X_GATHER_MUL) p0[0] = d.base + (long long)nidx0 * d.ld;
+            else p0[0] = d.base + (long long)r * d.ld;
+            if (KIND == X_GATHER_MUL) p1[0] = d.base + (long long)nidx1 * d.ld;
+            if (KIND == X_SOFTMAX) { mx[0] = d.mx[r]; }
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v0[i] = *(const f32x4u*)(p0[0] + c + 32 * i);
+            if (KIND == X_GATHER_MUL) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) v1[i] = *(const f32x4u*)(p1[0] + c + 32 * i);
+            }
+            // gather indices of the k-step after this one
+            if (KIND == X_GATHER || KIND == X_GATHER_MUL) nidx0 = d.idx[min(r + GEMM_BK, rows - 1)];
+            if (KIND == X_GATHER_MUL) nidx1 = d.idx2[min(r + GEMM_BK, rows - 1)];
+        }
+    }
+    template <int KIND>
+    __device__ __forceinline__ void store_fast(float* lds, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int ri = COLK ? i : 0;
+            f32x4 v = v0[i];
+            if (KIND == X_GATHER_MUL) {
+                v = v * v1[i];
+            } else if (KIND == X_SOFTMAX) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[j], 1.44269504088896341f, -mx[ri]));
+            }
+            float* dst = COLK ? lds + (i * 32 + (tid >> 3)) * PITCH + 4 * (tid & 7)
+                              : lds + (tid >> 3) * PITCH + 4 * (tid & 7) + 32 * i;
+            *(f32x4*)dst = v;
+        }
+    }
+    // after a run of fast steps the generic path needs its bookkeeping back
+    __device__ __forceinline__ void resync_after_fast() { rowmask = COLK ? rowmask : 1u; full_k = true; }
+
     // transform + zero padding + write into the LDS tile; k = k position the registers were issued for
     __device__ __forceinline__ void store(float* lds, int k, int tid) const {
         const bool full = COLK ? full_k : full_o;
@@ -333,26 +381,110 @@ __global__ __launch_bounds__(256, 2) void seg_gemm_kernel(const GemmArgs args) {
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](int buf) {
+    // k order inside a 32-deep step: MFMA (t, e) takes k = 8t + 2*lk + e from lane group lk, for BOTH operands
+    // (any bijection works as long as A and B agree).  A col-is-k tile then serves two MFMAs per ds_read_b64
+    // (pitch 36: 36*i mod 64 hits 16 distinct multiples of 4, + 2*lk + e: conflict-free over a 32-lane half).
+    auto compute_range = [&](int buf, int t0, int t1) {
         const float* pa = lds_a + buf * Cfg::A_ELEMS;
         const float* pb = lds_b + buf * Cfg::B_ELEMS;
 #pragma unroll
-        for (int k4 = 0; k4 < BK / 4; ++k4) {
-            float af[WM], bf[WN];
-            const int kk = k4 * 4 + lk;
+        for (int t = t0; t < t1; ++t) {
+            f32x2 af[WM], bf[WN];
+            const int kk = t * 8 + 2 * lk;
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
-                af[i] = A_COLK ? pa[(wm0 + i * 16 + li) * PA + kk] : pa[kk * PA + wm0 + i * 16 + li];
+            for (int i = 0; i < WM; ++i) {
+                if (A_COLK) af[i] = *(const f32x2*)(pa + (wm0 + i * 16 + li) * PA + kk);
+                else af[i] = f32x2{pa[kk * PA + wm0 + i * 16 + li], pa[(kk + 1) * PA + wm0 + i * 16 + li]};
+            }
 #pragma unroll
-            for (int j = 0; j < WN; ++j)
-                bf[j] = B_COLK ? pb[(wn0 + j * 16 + li) * PB + kk] : pb[kk * PB + wn0 + j * 16 + li];
+            for (int j = 0; j < WN; ++j) {
+                if (B_COLK) bf[j] = *(const f32x2*)(pb + (wn0 + j * 16 + li) * PB + kk);
+                else bf[j] = f32x2{pb[kk * PB + wn0 + j * 16 + li], pb[(kk + 1) * PB + wn0 + j * 16 + li]};
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+    };
+    auto compute = [&](int buf) { compute_range(buf, 0, BK / 8); };
+
+    // LDS -> register fragments of sub-step t (8 k-values: two MFMAs per accumulator)
+    auto read_frags = [&](const float* pa, const float* pb, int t, f32x2 (&af)[WM], f32x2 (&bf)[WN]) {
+        const int kk = t * 8 + 2 * lk;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            if (A_COLK) af[i] = *(const f32x2*)(pa + (wm0 + i * 16 + li) * PA + kk);
+            else af[i] = f32x2{pa[kk * PA + wm0 + i * 16 + li], pa[(kk + 1) * PA + wm0 + i * 16 + li]};
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            if (B_COLK) bf[j] = *(const f32x2*)(pb + (wn0 + j * 16 + li) * PB + kk);
+            else bf[j] = f32x2{pb[kk * PB + wn0 + j * 16 + li], pb[(kk + 1) * PB + wn0 + j * 16 + li]};
+        }
+    };
+    auto mfma_frags = [&](const f32x2 (&af)[WM], const f32x2 (&bf)[WN]) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
     };
+    constexpr int NREADS = (A_COLK ? WM : 2 * WM) + (B_COLK ? WN : 2 * WN);   // ds_read instructions per sub-step
+    constexpr int NMFMA = 2 * WM * WN;                                          // MFMAs per sub-step
+
+    // One interior k-step with compile-time operand kinds.  Hand-pinned software pipeline (one wave per SIMD
+    // has nobody else to hide its stalls):
+    //   global loads of tile t+1  |  sub-steps 0..2: fragment reads run one sub-step ahead of their MFMAs  |
+    //   sub-step 3's MFMAs interleaved with the transform (exp2 / product) + ds_write of tile t+1  |  barrier
+    auto fast_run = [&](auto akind_c, auto bkind_c, int nfast, int& buf) {
+        constexpr int AK = decltype(akind_c)::value, BKD = decltype(bkind_c)::value;
+        const XDesc& da = adesc(seg);
+        const XDesc& db = args.b[seg];
+        for (int it = 0; it < nfast; ++it) {
+            kpos += BK;
+            const float* pa = lds_a + buf * Cfg::A_ELEMS;
+            const float* pb = lds_b + buf * Cfg::B_ELEMS;
+            f32x2 af0[WM], bf0[WN], af1[WM], bf1[WN];
+            la.template issue_fast<AK>(da, kpos, tid);
+            lb.template issue_fast<BKD>(db, kpos, tid);
+            read_frags(pa, pb, 0, af0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(pa, pb, 1, af1, bf1);
+            mfma_frags(af0, bf0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(pa, pb, 2, af0, bf0);
+            mfma_frags(af1, bf1);
+            __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(pa, pb, 3, af1, bf1);
+            mfma_frags(af0, bf0);
+            __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            la.template store_fast<AK>(lds_a + (buf ^ 1) * Cfg::A_ELEMS, tid);
+            lb.template store_fast<BKD>(lds_b + (buf ^ 1) * Cfg::B_ELEMS, tid);
+            mfma_frags(af1, bf1);
+#pragma unroll
+            for (int q = 0; q < NMFMA; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     // up to 4 VALU in its shadow
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // up to 1 ds_write
+            }
+            __syncthreads();
+            buf ^= 1;
+        }
+        la.resync_after_fast(); lb.resync_after_fast();
+    };
+    const bool tile_interior = m0 + BM <= M && n0 + BN <= N;
 
     // ---- main loop ------------------------------------------------------------------------------
     if (step_begin < step_end) {
@@ -368,7 +500,42 @@ __global__ __launch_bounds__(256, 2) void seg_gemm_kernel(const GemmArgs args) {
         lb.store(lds_b, kpos, tid);
         __syncthreads();
         int buf = 0;
-        for (int step = step_begin; step < step_end; ++step) {
+        int step = step_begin;
+        while (step < step_end) {
+            // interior stretch: steps whose NEXT tile is a full tile of the same segment
+            int nfast = 0;
+            if (tile_interior) {
+                const int in_seg = args.klen[seg] / BK - 1 - kpos / BK;      // full tiles after the current one
+                nfast = min(step_end - 1 - step, in_seg);
+                // row-is-k operands: the reduction rows of every fast tile must exist (klen == rows there)
+            }
+            if (nfast > 0) {
+                const int ak = la.kind == X_GATHER && A_COLK ? (int)X_PLAIN : la.kind;
+                const int bk = lb.kind == X_GATHER && B_COLK ? (int)X_PLAIN : lb.kind;
+                bool done = true;
+                typedef std::integral_constant<int, X_PLAIN> KP;
+                typedef std::integral_constant<int, X_GATHER> KG;
+                typedef std::integral_constant<int, X_GATHER_MUL> KM;
+                typedef std::integral_constant<int, X_SOFTMAX> KS;
+                if (bk == X_PLAIN) {
+                    if (ak == X_PLAIN) fast_run(KP{}, KP{}, nfast, buf);
+                    else if (A_COLK && B_COLK && ak == X_GATHER_MUL) fast_run(KM{}, KP{}, nfast, buf);
+                    else if (A_COLK && B_COLK && ak == X_SOFTMAX) fast_run(KS{}, KP{}, nfast, buf);
+                    else done = false;
+                } else if (!A_COLK && !B_COLK && ak == X_PLAIN) {
+                    if (bk == X_GATHER) fast_run(KP{}, KG{}, nfast, buf);
+                    else if (bk == X_GATHER_MUL) fast_run(KP{}, KM{}, nfast, buf);
+                    else if (bk == X_SOFTMAX) fast_run(KP{}, KS{}, nfast, buf);
+                    else done = false;
+                } else {
+                    done = false;
+                }
+                if (done) {
+                    step += nfast;
+                    // re-arm the generic path's index prefetch for the step after the current tile
+                    continue;
+                }
+            }
             const bool has_next = step + 1 < step_end;
             int nkpos = kpos + BK, nseg = seg;
             if (has_next) {
@@ -390,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void seg_gemm_kernel(const GemmArgs args) {
                 lb.store(lds_b + (buf ^ 1) * Cfg::B_ELEMS, nkpos, tid);
             }
             __syncthreads();
-            buf ^= 1; seg = nseg; kpos = nkpos;
+            buf ^= 1; seg = nseg; kpos = nkpos; ++step;
         }
     }
 
