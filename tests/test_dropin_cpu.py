@@ -1,0 +1,149 @@
+"""CPU: host logic of the drop-in surface (no compute): plugin API, config merge, DP sharding, gloo all-reduce."""
+import inspect
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+import yaml
+
+from conftest import PKG, ROOT
+from oracle import ncx_oracle as orc
+
+
+def _tiny_opt():
+    return dict(arch="MutanNoAtt", seq2vec=dict(arch="gru", emb_size=8, dropout=0.0),
+                fusion=dict(dim_v=64, dim_q=48, dim_hv=16, dim_hq=16, dim_mm=16, R=3, dropout_v=0.5, dropout_q=0.5,
+                            activation_v="tanh", activation_q="tanh", dropout_hv=0, dropout_hq=0),
+                classif=dict(dropout=0.5))
+
+
+def test_plugin_surface_and_state_dict_keys():
+    import vqa.models as M
+    from vqa.models.cx import CXModelBase, DistanceBaseline, NeuralModel, RandomBaseline
+    assert "MutanNoAtt" in M.model_names
+    sig = inspect.signature(M.factory)
+    assert list(sig.parameters) == ["opt", "vocab_words", "vocab_answers", "cuda", "data_parallel"]   # utils.py:14
+    vqa = M.factory(_tiny_opt(), ["w%d" % i for i in range(10)], ["a%d" % i for i in range(20)], cuda=False, data_parallel=False)
+    for attr in ("seq2vec", "_fusion", "_classif", "opt", "vocab_answers"):
+        assert hasattr(vqa, attr)
+    spec = dict(v_emb=True, v_mult=True, v_dist=True, v_rank=True, q_emb=True, a_emb=True, z_emb=True)
+    for L in (1, 2, 3):
+        m = NeuralModel(model_spec=spec, dim_h=16, n_layers=L, emb=None, drop_p=0.25, vqa_model=vqa, knn_size=24, trainable_vqa=False)
+        assert isinstance(m, CXModelBase) and m.knn_size == 24
+        d = orc.Dims(dv=64, dq=48, dz=16, A=20, H=16, L=L)
+        own = {k: tuple(v.shape) for k, v in m.state_dict().items() if not k.startswith("vqa_model.")}
+        assert own == orc.param_shapes(d)                      # names + shapes of cx.py:240-257
+        assert any(k.startswith("vqa_model.") for k in m.state_dict())      # registered submodule (cx.py:56)
+        assert all(not p.requires_grad or not n.startswith("vqa_model.") or True for n, p in m.named_parameters())
+    assert list(inspect.signature(NeuralModel.forward).parameters) == ["self", "image_features", "question_wids", "answer_aids"]
+    with pytest.raises(NotImplementedError):
+        NeuralModel(model_spec=spec, dim_h=16, n_layers=1, emb=None, drop_p=0.0, vqa_model=vqa, knn_size=24, trainable_vqa=True)
+    # known-answer baselines (cx.py:20-44)
+    s = DistanceBaseline(24)(torch.zeros(3, 25, 4), None, None)
+    assert torch.equal(s[0], torch.arange(23, -1, -1, dtype=torch.float32))
+    gt = torch.tensor([0, 4, 5])
+    assert (orc.recall_at_k(s, gt, 5) == np.array([1, 1, 0])).all()
+    assert RandomBaseline(24)(torch.zeros(3, 25, 4), None, None).shape == (3, 24)
+
+
+def test_forward_without_gpu_fails_loudly():
+    """No CPU fallback: scoring with CPU tensors must raise, not silently compute."""
+    import vqa.models as M
+    from neuralcx import NcxError
+    from vqa.models.cx import NeuralModel
+    vqa = M.factory(_tiny_opt(), ["w%d" % i for i in range(10)], ["a%d" % i for i in range(20)], cuda=False, data_parallel=False)
+    spec = dict(v_emb=True, v_mult=True, v_dist=True, v_rank=True, q_emb=True, a_emb=True, z_emb=True)
+    m = NeuralModel(model_spec=spec, dim_h=16, n_layers=1, emb=None, drop_p=0.0, vqa_model=vqa, knn_size=24, trainable_vqa=False)
+    with pytest.raises(NcxError):
+        m(torch.rand(2, 25, 64), torch.ones(2, 26, dtype=torch.long), torch.zeros(2, dtype=torch.long))
+
+
+def test_update_values_semantics():
+    from vqa.lib.utils import update_values
+    y = {"optim": {"lr": 1e-4, "batch_size": 64}, "cx_model": {"dim_h": 256}}
+    out = update_values({"optim": {"lr": None, "batch_size": 512}, "extra": {"a": 1}}, y)
+    assert out["optim"] == {"lr": 1e-4, "batch_size": 512} and out["extra"] == {"a": 1}     # None never overrides
+
+
+def test_cli_options_and_shipped_yaml_schema():
+    import counterexamples as cli
+    for f in os.listdir(os.path.join(PKG, "options", "cx")):
+        a = cli.build_parser().parse_args(["--synthetic", "--path_opt", os.path.join(PKG, "options", "cx", f), "-b", "512"])
+        o = cli.load_options(a)
+        assert o["optim"]["batch_size"] == 512 and o["optim"]["lr"] == 1e-4
+        for k in ("name", "dim_h", "n_layers", "drop_p", "v_emb", "v_mult", "v_dist", "v_rank", "q_emb", "a_emb", "z_emb"):
+            assert k in o["cx_model"]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/options/cx"), reason="reference checkout only exists in the build container")
+def test_reference_yaml_files_load_unchanged():
+    import counterexamples as cli
+    d = "/root/reference/options/cx"
+    n = 0
+    for f in sorted(os.listdir(d)):
+        a = cli.build_parser().parse_args(["--synthetic", "--path_opt", os.path.join(d, f)])
+        o = cli.load_options(a)
+        assert o["cx_model"]["dim_h"] in (256, 300, 512, 1024) and o["cx_model"]["n_layers"] in (1, 2, 3)
+        assert o["model"]["arch"] == "MutanNoAtt" and o["model"]["fusion"]["dim_mm"] == 360
+        n += 1
+    assert n == 19
+
+
+def test_epoch_batches_and_shards_cover_every_example_once():
+    from neuralcx import dp
+    b = dp.epoch_batches(1003, 64, epoch=3)
+    assert len(b) == 16 and len(b[-1]) == 1003 - 15 * 64          # last partial batch kept (batchify :513-515)
+    assert sorted(i for x in b for i in x) == list(range(1003))
+    assert b == dp.epoch_batches(1003, 64, epoch=3) and b != dp.epoch_batches(1003, 64, epoch=4)
+    for world in (1, 2, 3, 8):
+        for ids in (b[0], b[-1]):
+            parts = [dp.shard(ids, r, world) for r in range(world)]
+            assert [i for p in parts for i in p] == ids
+            assert max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path[:0] = [ROOT, PKG, os.path.join(ROOT, "tests")]
+    import torch.distributed as dist
+    from neuralcx import dp
+    from oracle import ncx_oracle as orc
+    from helpers import load_golden
+    dp.init_distributed(backend="gloo")
+    g, d, spec, params, batch = load_golden("g1_small_L2")
+    B = batch["gt"].shape[0]
+    ids = dp.shard(list(range(B)), rank, world)
+    sub = {k: v[ids] for k, v in batch.items()}
+    # local loss scaled by 1/B_global (ncx_dims.loss_scale): sum-all-reduce == global-batch gradient
+    leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    s = orc.forward_faithful(leaf, d, sub["image_features"], sub["q_emb"], sub["z_orig"], sub["z_knns"], sub["a_knns"], sub["answer_aids"], spec=spec)
+    loss = torch.nn.functional.cross_entropy(s, sub["gt"], reduction="sum") / B
+    loss.backward()
+    names = list(leaf)
+    flat = torch.cat([leaf[n].grad.reshape(-1) for n in names])
+    dp.allreduce_sum_(flat, bucket_elems=50000)                    # bucketed path
+    l, h1, h5, n = dp.reduce_metrics(float(loss) * B, 1, 2, len(ids), torch.device("cpu"))
+    if rank == 0:
+        q.put((flat.numpy(), l, n))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_dp2_gloo_matches_single_process_gradient():
+    """world_size 2 over gloo: sharded loss/B_global + SUM all-reduce == the golden single-process gradient."""
+    from helpers import load_golden
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    flat, l, n = q.get(timeout=120)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    g, d, spec, params, batch = load_golden("g1_small_L2")
+    ref = np.concatenate([g["grad/" + k].reshape(-1) for k in params])
+    assert n == batch["gt"].shape[0]
+    assert abs(l / n - float(g["loss"])) < 1e-5
+    assert np.abs(flat - ref).max() <= 1e-6 * max(np.abs(ref).max(), 1.0)

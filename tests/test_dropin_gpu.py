@@ -1,0 +1,132 @@
+"""GPU: the reference-shaped surfaces on top of the HIP path -- NeuralModel (nn.Module + autograd),
+the training engine over several steps (loss curve + Recall@5 vs the CPU oracle), and the CLI."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import PKG
+from oracle import ncx_oracle as orc
+from helpers import GRAD_FLOOR
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _tiny_opt(dv=64, dq=48, dz=16):
+    return dict(arch="MutanNoAtt", seq2vec=dict(arch="gru", emb_size=8, dropout=0.0),
+                fusion=dict(dim_v=dv, dim_q=dq, dim_hv=dz, dim_hq=dz, dim_mm=dz, R=3, dropout_v=0.5, dropout_q=0.5,
+                            activation_v="tanh", activation_q="tanh", dropout_hv=0, dropout_hq=0),
+                classif=dict(dropout=0.5))
+
+
+@pytest.mark.parametrize("L", [1, 3])
+def test_neuralmodel_module_forward_and_autograd(L):
+    import vqa.models as M
+    from vqa.models.cx import NeuralModel
+    torch.manual_seed(0)
+    A, B = 20, 6
+    vqa = M.factory(_tiny_opt(), ["w%d" % i for i in range(30)], ["a%d" % i for i in range(A)], cuda=True, data_parallel=False)
+    spec = dict(v_emb=True, v_mult=True, v_dist=True, v_rank=True, q_emb=True, a_emb=True, z_emb=True)
+    m = NeuralModel(model_spec=spec, dim_h=16, n_layers=L, emb=None, drop_p=0.25, vqa_model=vqa, knn_size=24, trainable_vqa=False).cuda()
+    d = orc.Dims(dv=64, dq=48, dz=16, A=A, H=16, L=L)
+    params = orc.init_params(d, seed=3, gain=3.0)
+    m.load_state_dict({**{k: v for k, v in m.state_dict().items() if k.startswith("vqa_model.")}, **params})
+    m.eval()                                                     # dropout off (cx_model.eval(), counterexamples.py:451)
+    feats = (torch.randn(B, 25, 64).abs() * 0.45).to(DEV)
+    wids = torch.zeros(B, 26, dtype=torch.long)
+    for b in range(B):
+        n = 3 + b
+        wids[b, :n] = torch.randint(1, 31, (n,))
+    wids = wids.to(DEV)
+    aids = torch.randint(0, A, (B,)).to(DEV)
+    gt = torch.randint(0, 24, (B,)).to(DEV)
+    scores = m(feats, wids, aids)                                # reference call signature (cx.py:261)
+    assert scores.shape == (B, 24)
+    loss = torch.nn.CrossEntropyLoss(reduction="sum")(scores, gt) / B          # counterexamples.py:310,334
+    m.zero_grad()
+    loss.backward()                                              # counterexamples.py:338 -> ncx_backward
+    a_o, z_o, a_k, z_k, q = [t.cpu() for t in m.vqa_forward(feats, wids)]
+    batch = dict(image_features=feats.cpu(), q_emb=q, z_orig=z_o, z_knns=z_k, a_knns=a_k, answer_aids=aids.cpu(), gt=gt.cpu())
+    s_ref, l_ref, g_ref = orc.loss_and_grads(params, d, batch)
+    assert float((scores.detach().cpu() - s_ref).abs().max()) <= 1e-4
+    assert abs(float(loss.detach()) - float(l_ref)) <= 1e-5
+    own = {n: p for n, p in m.named_parameters() if not n.startswith("vqa_model.")}
+    for n, p in own.items():
+        ref = g_ref[n]
+        tol = 1e-4 * max(float(ref.abs().max()), GRAD_FLOOR)
+        assert float((p.grad.cpu() - ref).abs().max()) <= tol, n
+    for n, p in m.named_parameters():
+        if n.startswith("vqa_model."):
+            assert p.grad is None                                # frozen VQA model (cx.py:79-80)
+    # torch.optim.Adam on the module parameters works as in the reference (counterexamples.py:275-276)
+    opt = torch.optim.Adam([p for p in own.values()], lr=1e-4)
+    opt.step()
+    st = orc.AdamState()
+    new = orc.adam_update(params, {k: v for k, v in g_ref.items()}, st, lr=1e-4)
+    for n, p in own.items():
+        if n != "out.bias":      # zero gradient in maths; elsewhere ignore entries whose gradient is ~eps (Adam's sqrt(v)+1e-8)
+            big = g_ref[n].abs() > 1e-5 * g_ref[n].abs().max()
+            assert float((p.detach().cpu() - new[n]).abs()[big].max()) <= 2e-6, n
+
+
+def test_engine_training_matches_oracle_training():
+    """30 Adam steps with dropout (shared counter-based masks) on identical synthetic data: per-step loss within
+    1e-4 of the CPU oracle's training run, and Recall@1/@5 on held-out triplets identical (+-0.1 pt allowed)."""
+    from neuralcx import ops
+    from neuralcx.engine import NeuralCXEngine
+    d = orc.Dims(dv=64, dq=48, dz=16, A=20, H=32, L=2)
+    B, steps, p_drop, lr = 16, 30, 0.25, 1e-3
+    rng = np.random.default_rng(7)
+    t = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+
+    def make(n):
+        feats = np.abs(rng.standard_normal((n, d.K + 1, d.dv))) * 0.45
+        dist = np.linalg.norm(feats[:, :1] - feats[:, 1:], axis=2)
+        gt = dist.argmin(1)                                         # learnable: the closest candidate
+        return dict(image_features=t(feats), q_emb=t(rng.standard_normal((n, d.dq)) * 0.3), z_orig=t(rng.standard_normal((n, d.dz))),
+                    z_knns=t(rng.standard_normal((n, d.K, d.dz))), a_knns=t(rng.standard_normal((n, d.K, d.A)) * 2),
+                    answer_aids=torch.from_numpy(rng.integers(0, d.A, size=n)), gt=torch.from_numpy(gt))
+    train = [make(B) for _ in range(5)]
+    held = make(64)
+    eng = NeuralCXEngine(K=d.K, dv=d.dv, dq=d.dq, dz=d.dz, da=d.da, A=d.A, H=d.H, L=d.L, drop_p=p_drop, lr=lr, device=DEV)
+    params = orc.init_params(d, seed=21, gain=2.0)
+    eng.load_state(params)
+    st = orc.AdamState()
+    cur = {k: v.clone() for k, v in params.items()}
+    to_batch = lambda bt: ops.Batch.from_dense(*[bt[k].to(DEV) for k in ("image_features", "q_emb", "z_orig", "z_knns", "a_knns", "answer_aids")])
+    for s in range(steps):
+        bt = train[s % len(train)]
+        r = eng.train_step(to_batch(bt), bt["gt"].to(DEV).to(torch.int32))
+        seed = (eng.seed << 32) ^ eng.step_count
+        masks = [orc.dropout_keep_mask(seed, l, B * d.K, d.H, p_drop) for l in range(1, d.L + 1)]
+        cur, _, l_ref, _ = orc.train_step(cur, d, bt, st, lr=lr, drop_p=p_drop, keep_masks=masks)
+        assert abs(float(r["loss"]) - float(l_ref)) <= 1e-4, (s, float(r["loss"]), float(l_ref))
+    ev = eng.eval_step(to_batch(held), held["gt"].to(DEV).to(torch.int32))
+    s_ref = orc.forward_faithful(cur, d, held["image_features"], held["q_emb"], held["z_orig"], held["z_knns"], held["a_knns"], held["answer_aids"])
+    assert float((ev["scores"].cpu() - s_ref).abs().max()) <= 1e-3          # 30 steps of Adam on both sides
+    for k, i in ((1, 0), (5, 1)):
+        r_hip = 100.0 * int(ev["hits"][i]) / 64
+        r_ref = 100.0 * orc.recall_at_k(s_ref, held["gt"], k).sum() / 64
+        assert abs(r_hip - r_ref) <= 0.1 + 1e-9, (k, r_hip, r_ref)
+    l_held = float(orc.ranking_loss(s_ref, held["gt"]))
+    assert abs(float(ev["loss"]) - l_held) <= 1e-3
+
+
+def test_cli_synthetic_smoke(tmp_path, capsys):
+    import counterexamples as cli
+    cli.main(["--synthetic", "--path_opt", os.path.join(PKG, "options", "cx", "neuralcx_256_1_all.yaml"), "-b", "64",
+              "--epochs", "1", "--syn_train", "256", "--syn_val", "128", "--syn_images", "2048", "-p", "2", "-t",
+              "--project_dir", str(tmp_path)])
+    out = capsys.readouterr().out
+    assert "Epoch 1 train: loss:" in out and "Epoch 1 val: loss:" in out and "Saved checkpoint" in out
+    runs = os.listdir(os.path.join(str(tmp_path), "logs", "cx"))
+    assert len(runs) == 1
+    base = os.path.join(str(tmp_path), "logs", "cx", runs[0])
+    for sub in ("ckpt", "best"):
+        state = torch.load(os.path.join(base, sub, "model.ckpt"))
+        assert state["linear_1.weight"].shape == (256, 14089) and state["answer_embedding.weight"].shape == (2000, 2400)
+        info = torch.load(os.path.join(base, sub, "info.ckpt"))
+        assert {"loss", "recall"} <= set(info[-1])
+    assert os.path.exists(os.path.join(base, "final_results.txt"))

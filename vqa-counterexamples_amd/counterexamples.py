@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""NeuralCX training / evaluation driver -- CLI drop-in for the reference's counterexamples.py.
+
+Keeps the reference's flags (counterexamples.py:39-87), YAML schema (options/cx/*.yaml), seeds (:119-121),
+run-directory layout and checkpoint files (`logs/cx/<run>/{ckpt,best}/{model,info}.ckpt`, :550-580) and the
+printed metrics (`Epoch e mode: loss: x, recall: y`, :493-498).  The per-batch body of the train loop
+(:322-339) and of eval_model (:460-468) runs on the HIP engine (neuralcx.engine.NeuralCXEngine).
+
+Net-new: `--synthetic` (no datasets offline: synthetic feature table + triplets of the real shapes) and data
+parallelism: launch with `python -m torch.distributed.run --nproc-per-node N counterexamples.py ...`;
+every rank holds the feature table and a replica, gradients are summed over RCCL.
+
+Real-data mode expects what the reference's notebooks produce (trainset_augmented.pickle, valset_augmented*.pickle,
+{train,val}set.npy feature tables converted from the hdf5 files, since h5py is not available here) plus a trained
+VQA checkpoint; it is wired but cannot be exercised in this offline image.
+"""
+import argparse
+import json
+import os
+import pickle
+import random
+import shutil
+import sys
+import time
+
+import numpy as np
+import torch
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+if HERE not in sys.path:
+    sys.path.insert(0, HERE)
+
+import vqa.lib.utils as utils                     # noqa: E402
+import vqa.models as models                       # noqa: E402
+from neuralcx import dp, ops                      # noqa: E402
+from neuralcx.engine import NeuralCXEngine        # noqa: E402
+from neuralcx.synth import SyntheticCX            # noqa: E402
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Train/Evaluate NeuralCX counterexample models (MI355X HIP path)")
+    p.add_argument("--path_opt", default=os.path.join(HERE, "options", "cx", "neuralcx_256_1_all.yaml"), type=str)
+    p.add_argument("--vqa_model", default="mutan_noatt_train", type=str)
+    p.add_argument("--cx_model", default="NeuralModel", type=str, help="NeuralModel | RandomBaseline | DistanceBaseline")
+    p.add_argument("--pairwise", action="store_true")
+    p.add_argument("-dev", "--dev_mode", action="store_true", help="small train/val subsets")
+    p.add_argument("--pretrained_vqa", dest="pretrained_vqa", action="store_true")
+    p.add_argument("--untrained_vqa", dest="pretrained_vqa", action="store_false")
+    p.set_defaults(pretrained_vqa=None)
+    p.add_argument("--trainable_vqa", action="store_true")
+    p.add_argument("-lr", "--learning_rate", type=float, help="initial learning rate")
+    p.add_argument("-b", "--batch_size", type=int, help="mini-batch size (global, across all ranks)")
+    p.add_argument("--epochs", type=int, help="number of total epochs to run")
+    p.add_argument("--resume", type=str, default=None, help="run name to resume")
+    p.add_argument("--best", action="store_true", help="resume the best checkpoint")
+    p.add_argument("-c", "--comment", type=str, default="")
+    p.add_argument("-p", "--print_freq", default=10, type=int)
+    p.add_argument("-v", "--eval_freq", default=-1, type=int)
+    p.add_argument("-t", "--test", action="store_true", help="evaluate the best model on the full validation set")
+    p.add_argument("--viz", action="store_true")
+    p.add_argument("--project_dir", default=os.getcwd(), type=str)
+    # net-new
+    p.add_argument("--synthetic", action="store_true", help="synthetic data of the real shapes (no datasets offline)")
+    p.add_argument("--syn_train", type=int, default=16384)
+    p.add_argument("--syn_val", type=int, default=4096)
+    p.add_argument("--syn_images", type=int, default=82783)
+    p.add_argument("--max_steps", type=int, default=-1, help="stop an epoch early (smoke runs)")
+    return p
+
+
+def load_options(args):
+    options = {"optim": {"lr": args.learning_rate, "batch_size": args.batch_size, "epochs": args.epochs},
+               "cx_model": {"pretrained_vqa": args.pretrained_vqa, "trainable_vqa": args.trainable_vqa or None}}
+    with open(args.path_opt) as f:
+        from_yaml = yaml.safe_load(f)          # the reference's yaml.load(handle) breaks on PyYAML >= 6
+    return utils.update_values(options, from_yaml)
+
+
+def recall_from_rank(rank, k):
+    return (rank < k)
+
+
+class Runner:
+    def __init__(self, args, options):
+        self.args, self.opt = args, options
+        self.rank, self.world, self.local = dp.init_distributed()
+        if not torch.cuda.is_available():
+            raise SystemExit("counterexamples.py: an MI355X is required (the HIP path has no CPU fallback)")
+        torch.cuda.set_device(self.local)
+        self.dev = torch.device("cuda", self.local)
+        random.seed(42); torch.manual_seed(42); torch.cuda.manual_seed(42)          # counterexamples.py:119-121
+        cx = options["cx_model"]
+        fus = options["model"]["fusion"]
+        self.K = 24
+        self.engine = NeuralCXEngine(K=self.K, dv=fus["dim_v"], dq=fus["dim_q"], dz=fus["dim_mm"], da=2400,
+                                     A=options["vqa"]["nans"], H=cx["dim_h"], L=cx["n_layers"], drop_p=cx["drop_p"],
+                                     lr=options["optim"]["lr"], device=self.dev,
+                                     spec={k: cx.get(k, True) for k in ("v_mult", "v_dist", "v_rank", "a_emb")},
+                                     world_size=self.world)
+        self.engine.rank = self.rank
+        self.engine.init_parameters(seed=42)
+        self.gb = options["optim"]["batch_size"]
+
+    def log(self, *a):
+        if self.rank == 0:
+            print(*a, flush=True)
+
+    # ---- data -----------------------------------------------------------------------------------------------
+    def load_synthetic(self):
+        a = self.args
+        fus = self.opt["model"]["fusion"]
+        kw = dict(K=self.K, dv=fus["dim_v"], dq=fus["dim_q"], dz=fus["dim_mm"], A=self.opt["vqa"]["nans"], device=self.dev)
+        n_tr = 1024 if a.dev_mode else a.syn_train
+        self.train = SyntheticCX(n_triplets=n_tr, n_img=a.syn_images, seed=1234, **kw)
+        self.val = SyntheticCX(n_triplets=a.syn_val, n_img=a.syn_images, seed=4321, feats=self.train.feats, **kw)
+
+    # ---- loops ----------------------------------------------------------------------------------------------
+    def run_epoch(self, epoch):
+        eng, tr = self.engine, self.train
+        batches = dp.epoch_batches(tr.N, self.gb, epoch, seed=42)
+        t0 = time.time(); seen = 0
+        acc = torch.zeros(3, dtype=torch.float64, device=self.dev)        # loss*B_local, hits5, count (no host sync)
+        for bi, ids in enumerate(batches):
+            if 0 <= self.args.max_steps <= bi:
+                break
+            mine = dp.shard(ids, self.rank, self.world)
+            if not mine:
+                continue
+            b, gt = tr.batch(torch.tensor(mine))
+            r = eng.train_step(b, gt, global_batch=len(ids))
+            acc[0] += r["loss"][0].double() * len(ids); acc[1] += r["hits"][1].double(); acc[2] += len(mine)
+            seen += len(ids)
+            if (bi + 1) % self.args.print_freq == 0:
+                l, _, h5, n = dp.reduce_metrics(float(acc[0]), 0, int(acc[1]), int(acc[2]), self.dev)
+                self.log("Epoch {} train: loss: {:.4f}, recall: {:.4f}, triplets/s: {:.0f}".format(
+                    epoch, l / max(n, 1), h5 / max(n, 1), seen / (time.time() - t0)))
+                acc.zero_()
+            if self.args.eval_freq > 0 and (bi + 1) % self.args.eval_freq == 0:
+                self.report("val", epoch, self.evaluate(self.val))
+        torch.cuda.synchronize()
+        return seen / (time.time() - t0)
+
+    def evaluate(self, data):
+        eng = self.engine
+        tot = torch.zeros(4, dtype=torch.float64, device=self.dev)
+        for ids in dp.epoch_batches(data.N, self.gb, 0, shuffle=False):
+            mine = dp.shard(ids, self.rank, self.world)
+            if not mine:
+                continue
+            b, gt = data.batch(torch.tensor(mine))
+            r = eng.eval_step(b, gt)
+            tot[0] += r["loss_rows"].double().sum() * len(mine); tot[1] += r["hits"][0]; tot[2] += r["hits"][1]; tot[3] += len(mine)
+        l, h1, h5, n = dp.reduce_metrics(float(tot[0]), int(tot[1]), int(tot[2]), int(tot[3]), self.dev)
+        return {"loss": l / n, "recall": h5 / n, "recall_1": h1 / n, "recall_5": h5 / n}
+
+    def report(self, mode, epoch, metrics):
+        self.log("Epoch {} {}: {}".format(epoch, mode, "".join("{}: {:.4f}, ".format(k, v) for k, v in metrics.items())))
+
+    # ---- checkpoints (counterexamples.py:550-580) -------------------------------------------------------------
+    def save(self, save_dir, info, is_best):
+        if self.rank != 0:
+            return
+        os.makedirs(os.path.join(save_dir, "ckpt"), exist_ok=True); os.makedirs(os.path.join(save_dir, "best"), exist_ok=True)
+        pm, pi = os.path.join(save_dir, "ckpt", "model.ckpt"), os.path.join(save_dir, "ckpt", "info.ckpt")
+        torch.save({k: v.cpu() for k, v in self.engine.state_dict().items()}, pm)
+        torch.save(info, pi)
+        if is_best:
+            shutil.copyfile(pm, os.path.join(save_dir, "best", "model.ckpt"))
+            shutil.copyfile(pi, os.path.join(save_dir, "best", "info.ckpt"))
+        self.log("{}Saved checkpoint to {}".format("* " if is_best else "", save_dir))
+
+    def load(self, save_dir, best):
+        sub = "best" if best else "ckpt"
+        state = torch.load(os.path.join(save_dir, sub, "model.ckpt"), map_location="cpu")
+        self.engine.load_state({k: v for k, v in state.items() if not k.startswith("vqa_model.")})
+        info = torch.load(os.path.join(save_dir, sub, "info.ckpt"))
+        assert len(info) > 0
+        last = info[-1]
+        return info, len(info) + 1, last.get("recall_5", last.get("recall"))     # the reference KeyErrors here (:580)
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    options = load_options(args)
+    if args.cx_model != "NeuralModel":
+        raise SystemExit("only --cx_model NeuralModel runs on the HIP path (baselines: vqa.models.cx.RandomBaseline / DistanceBaseline)")
+    if args.pairwise or args.viz:
+        raise SystemExit("--pairwise / --viz are outside the accelerated path (SURVEY 8: out of scope)")
+    if not args.synthetic:
+        raise SystemExit("real-data mode needs the VQA-CX pickles and feature tables, which are not available offline; "
+                         "use --synthetic")
+    r = Runner(args, options)
+    run = args.resume or "{}_{}".format(options["cx_model"].get("name", "neuralcx"), time.strftime("%m%d_%H%M%S"))
+    save_dir = os.path.join(args.project_dir, "logs", "cx", run)
+    r.load_synthetic()
+    info, start_epoch, best_recall = [], 1, 0.0
+    if args.resume:
+        info, start_epoch, best_recall = r.load(save_dir, args.best)
+    r.log("=> Starting training... ({} GPU(s), global batch {}, {} train / {} val triplets)".format(
+        r.world, r.gb, r.train.N, r.val.N))
+    for epoch in range(start_epoch, options["optim"]["epochs"] + 1):
+        tps = r.run_epoch(epoch)
+        res = r.evaluate(r.val)
+        r.report("val", epoch, res)
+        r.log("Epoch {} throughput: {:.0f} triplets/s".format(epoch, tps))
+        info.append(res)
+        is_best = res["recall"] > best_recall
+        best_recall = max(best_recall, res["recall"])
+        r.save(save_dir, info, is_best)
+    if args.test:
+        r.load(save_dir, best=True)
+        res = r.evaluate(r.val)
+        r.report("test", len(info), res)
+        if r.rank == 0:
+            with open(os.path.join(save_dir, "final_results.txt"), "w") as f:
+                json.dump(res, f)
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier(); torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

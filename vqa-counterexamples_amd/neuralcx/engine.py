@@ -15,7 +15,7 @@ from typing import Dict, Optional
 
 import torch
 
-from . import ops
+from . import dp, ops
 from ._lib import NCX_F_ALL
 
 STATE_NAMES = ("answer_embedding.weight", "linear_1.weight", "linear_1.bias", "linear_2.weight", "linear_2.bias",
@@ -71,6 +71,7 @@ class NeuralCXEngine:
         self._ws = None
         self._ws_key = None
         self.seed = 42
+        self.rank = 0
 
     # ---- parameters --------------------------------------------------------------------------------------
     def init_parameters(self, seed=42, emb=None):
@@ -97,8 +98,7 @@ class NeuralCXEngine:
         c = self.cfg
         d = ops.make_dims(batch, H=c["H"], L=c["L"], da=c["da"], A=c["A"], flags=self.flags, training=training,
                           drop_p=self.drop_p if training else 0.0, loss_scale=loss_scale,
-                          seed=(self.seed << 32) ^ self.step_count)
-        key = (d.B, d.K, d.n_img >= 0)
+                          seed=(self.seed << 32) ^ (self.rank << 24) ^ self.step_count)
         need = ops.workspace_bytes(d) + 256
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -124,7 +124,7 @@ class NeuralCXEngine:
         r = ops.ranking_loss(scores, gt, scale=1.0 / gb)
         ops.backward(d, batch, self.params.fields(), self._ws, r["dscores"], self.grads.fields())
         if self.world_size > 1:
-            torch.distributed.all_reduce(self.grads.flat, group=self.pg)          # RCCL sum over xGMI
+            dp.allreduce_sum_(self.grads.flat, group=self.pg)                     # RCCL sum over xGMI
         ops.adam_step(self.params.flat, self.grads.flat, self.exp_avg, self.exp_avg_sq, self.step_count, lr=self.lr)
         r["scores"] = scores
         return r

@@ -1,1 +1,2 @@
-"""placeholder, filled below"""
+from .noatt import MutanNoAtt  # noqa: F401
+from .utils import factory, model_names  # noqa: F401
