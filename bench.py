@@ -157,7 +157,7 @@ def main():
         p_cols = 2 * c["dv"] + 1 + c["dz"] + c["A"]
         flops_main = 2.0 * M * c["H"] * p_cols
         names = {"MAIN": "seg_gemm NT 96x128 (linear_1 candidate segments, fwd)",
-                 "DW1C": "seg_gemm TN 128x128 (linear_1 candidate-column weight grad + dGt, incl. split-K reduce)"}
+                 "DW1C": "seg_gemm TN 128x128 stream-K (linear_1 candidate-column weight grad + dGt, incl. fix-up)"}
         per = {k: sum(v) / len(v) for k, v in prof.items() if v}
         dom = max(per, key=per.get) if per else None
         roof = None

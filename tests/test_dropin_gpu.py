@@ -105,7 +105,10 @@ def test_engine_training_matches_oracle_training():
         assert abs(float(r["loss"]) - float(l_ref)) <= 1e-4, (s, float(r["loss"]), float(l_ref))
     ev = eng.eval_step(to_batch(held), held["gt"].to(DEV).to(torch.int32))
     s_ref = orc.forward_faithful(cur, d, held["image_features"], held["q_emb"], held["z_orig"], held["z_knns"], held["a_knns"], held["answer_aids"])
-    assert float((ev["scores"].cpu() - s_ref).abs().max()) <= 1e-3          # 30 steps of Adam on both sides
+    # out.bias has a zero gradient in maths; Adam turns its round-off into +-lr per step, differently on every platform
+    # (SURVEY 7): after training, logits are compared modulo a per-row constant (ranking and loss are unaffected).
+    centred = lambda x: x - x.mean(1, keepdim=True)
+    assert float((centred(ev["scores"].cpu()) - centred(s_ref)).abs().max()) <= 1e-3      # 30 Adam steps on both sides
     for k, i in ((1, 0), (5, 1)):
         r_hip = 100.0 * int(ev["hits"][i]) / 64
         r_ref = 100.0 * orc.recall_at_k(s_ref, held["gt"], k).sum() / 64

@@ -11,6 +11,7 @@
 // Backward mirrors it (see ncx_backward).  Nothing here allocates or synchronises.
 #include "ncx_internal.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace ncx {
 
@@ -173,18 +174,38 @@ __global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict_
     const int ch = blockIdx.y, nch = gridDim.y;
     if (n >= N) return;
     const int r0 = (int)((long long)M * ch / nch), r1 = (int)((long long)M * (ch + 1) / nch);
-    float s = 0.f;
-    if (wgt) for (int r = r0; r < r1; ++r) s += x[(long long)r * N + n] * wgt[r];
-    else     for (int r = r0; r < r1; ++r) s += x[(long long)r * N + n];
-    partial[(long long)ch * N + n] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = r0;
+    if (wgt) {
+        for (; r + 3 < r1; r += 4) {
+            s0 += x[(long long)r * N + n] * wgt[r];           s1 += x[(long long)(r + 1) * N + n] * wgt[r + 1];
+            s2 += x[(long long)(r + 2) * N + n] * wgt[r + 2]; s3 += x[(long long)(r + 3) * N + n] * wgt[r + 3];
+        }
+        for (; r < r1; ++r) s0 += x[(long long)r * N + n] * wgt[r];
+    } else {
+        for (; r + 3 < r1; r += 4) {
+            s0 += x[(long long)r * N + n];       s1 += x[(long long)(r + 1) * N + n];
+            s2 += x[(long long)(r + 2) * N + n]; s3 += x[(long long)(r + 3) * N + n];
+        }
+        for (; r < r1; ++r) s0 += x[(long long)r * N + n];
+    }
+    partial[(long long)ch * N + n] = (s0 + s1) + (s2 + s3);
 }
+// out[n] = sum_ch partial[ch][n]: 32 threads per column (8 columns per block), fixed-order tree -> deterministic
 __global__ __launch_bounds__(256) void k_colsum_finish(const float* __restrict__ partial, int nch, int N,
                                                        float* __restrict__ out) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float red[32][9];
+    const int c = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const int n = blockIdx.x * 8 + c;
     float s = 0.f;
-    for (int c = 0; c < nch; ++c) s += partial[(long long)c * N + n];
-    out[n] = s;
+    if (n < N) for (int ch = g; ch < nch; ch += 32) s += partial[(long long)ch * N + n];
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && n < N) {
+        float t = 0.f;
+        for (int i = 0; i < 32; ++i) t += red[i][c];
+        out[n] = t;
+    }
 }
 // out[0] = sum(x[0..n)); single block.
 __global__ __launch_bounds__(256) void k_sum_vec(const float* __restrict__ x, int n, float* __restrict__ out) {
@@ -207,23 +228,6 @@ __global__ __launch_bounds__(256) void k_rowgroup_sum(const float* __restrict__ 
     float s = 0.f;
     for (int k = 0; k < K; ++k) s += p[(long long)k * H];
     dsh[i] = s;
-}
-
-// Sum split-K slabs and scatter the column ranges to their destinations (+ optional bias per column).
-struct ReduceRange { const float* src; float* dst; const float* bias; long long lds, ldd; int cols; int col0; };
-struct ReduceArgs { ReduceRange r[NCX_MAX_SEG]; int nr; int rows; int ksplit; long long split_stride; int total_cols; };
-__global__ __launch_bounds__(256) void k_slab_reduce(const ReduceArgs a) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)a.rows * a.total_cols) return;
-    const int row = (int)(i / a.total_cols);
-    int c = (int)(i - (long long)row * a.total_cols);
-    int q = 0;
-    while (q + 1 < a.nr && c >= a.r[q + 1].col0) ++q;
-    c -= a.r[q].col0;
-    const float* s = a.r[q].src + (long long)row * a.r[q].lds + c;
-    float v = a.r[q].bias ? a.r[q].bias[c] : 0.f;
-    for (int z = 0; z < a.ksplit; ++z) v += s[(long long)z * a.split_stride];
-    a.r[q].dst[(long long)row * a.r[q].ldd + c] = v;
 }
 
 // dst[aid[b]][:] += src[b][:], deterministically: the first occurrence of an id owns the row and adds
@@ -301,25 +305,51 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 // =================================================================================================
 static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
 
-// tiles_big / tiles_small: output tiles with 128x128 / 64x64 blocks; ksteps: 32-deep reduction steps.
+// Split planning.  A problem whose whole tiles cannot fill the chip is split along K into S aligned chunks and
+// run as W = tiles*S workgroups through the stream-K path (unit ranges of W = tiles*S workgroups coincide with
+// the chunks, so workgroups working on the same chunk of different tiles share their operand rows in L2 --
+// unaligned stream-K ranges lose that sharing and ran 1.3x slower).  S minimises a makespan estimate:
+// workgroups per busiest CU x k-steps per workgroup / MFMA efficiency at that residency.
+static int choose_split(long long tiles, long long ksteps, int occ) {
+    static const double eff[4] = {1.0, 0.60, 0.85, 0.90};
+    double best = 1e30; int best_s = 1;
+    const long long smax = ksteps / 8 > 1 ? ksteps / 8 : 1;
+    for (long long sp = 1; sp <= smax && sp <= 64; ++sp) {
+        const long long wgs = tiles * sp;
+        const double steps = (double)cdiv(ksteps, sp) + 4.0;            // + pipeline prologue/epilogue
+        long long per_cu = cdiv(wgs, 256);
+        double t;
+        if (per_cu <= occ) t = per_cu * steps / eff[per_cu];
+        else t = (double)cdiv(wgs, 256 * occ) * occ * steps / eff[occ];
+        t += 0.02 * sp * steps;                                          // partial-tile traffic + fix-up
+        if (t < best - 1e-9) { best = t; best_s = (int)sp; }
+    }
+    return best_s;
+}
+
+// tiles_big / tiles_small: output tiles with 128x128 / 64x64 blocks; ksteps: 32-deep reduction steps per tile.
 static GemmPlan plan_from_tiles(long long tiles_big, long long tiles_small, long long ksteps, bool big_ok) {
-    const long long target = 512;                        // ~2 resident workgroups per CU
-    const long long max_split = ksteps / 4 > 1 ? ksteps / 4 : 1;
-    GemmPlan p;
-    if (big_ok && tiles_big >= 160) { p.cfg = CFG_128x128; p.ksplit = 1; return p; }
-    long long sb = cdiv(target, tiles_big);   if (sb > max_split) sb = max_split;
-    long long ss = cdiv(target, tiles_small); if (ss > max_split) ss = max_split;
-    if (ss > 64) ss = 64;
-    if (sb > 64) sb = 64;
-    if (big_ok && tiles_big * sb >= 256) { p.cfg = CFG_128x128; p.ksplit = (int)sb; return p; }
-    p.cfg = CFG_64x64; p.ksplit = (int)ss;
+    GemmPlan p; p.ksplit = 1; p.sk_wgs = 0;
+    if (big_ok && tiles_big >= 192 && ksteps >= 64) { p.cfg = CFG_128x128; return p; }
+    // Measured on MI355X (DW1C, 104 big / 412 small tiles x 384 k-steps): the 128x128 TN/NT instantiations spill
+    // (233 VGPRs) and reach 0.75-0.81 ms at any split, the spill-free 64x64 tile 0.57 ms at 4 chunks.  Until the
+    // big-tile kernel is slimmed down, split problems use 64x64 tiles with ~6 resident workgroups' worth of
+    // work per CU.
+    (void)big_ok;
+    p.cfg = CFG_64x64;
+    const long long tiles = tiles_small;
+    long long sp = cdiv(1536, tiles);
+    const long long smax = ksteps / 8 > 1 ? ksteps / 8 : 1;
+    if (sp > smax) sp = smax;
+    if (tiles >= 1024) sp = 1;
+    if (sp > 1) p.sk_wgs = (int)(tiles * sp);
     return p;
 }
 
 GemmPlan plan_gemm(int form, long long M, long long N, long long ksteps, bool allow_96) {
     if (form == FORM_NT && allow_96 && M % 96 == 0 && N % 128 == 0 && (M / 96) * (N / 128) >= 192 &&
         (M % 128 != 0 || cdiv(M, 128) * cdiv(N, 128) < 256)) {
-        GemmPlan p; p.cfg = CFG_96x128; p.ksplit = 1; return p;
+        GemmPlan p; p.cfg = CFG_96x128; p.ksplit = 1; p.sk_wgs = 0; return p;
     }
     const bool big_ok = M >= 96 && N >= 96;
     return plan_from_tiles(cdiv(M, 128) * cdiv(N, 128), cdiv(M, 64) * cdiv(N, 64), ksteps, big_ok);
@@ -350,9 +380,41 @@ static void list_uses(const ncx_dims& d, GemmUse* u) {
     u[U_DWL]   = {FORM_TN, H, H, ks(M), false};
     u[U_DXL]   = {FORM_NN, M, H, ks(H), false};
     for (int i = 0; i < U_COUNT; ++i) {
-        u[i].plan = plan_gemm(u[i].form, u[i].M, u[i].N, u[i].ksteps, u[i].allow96);
-        if (i == U_MAIN || i == U_FWD_L || i == U_DXL) u[i].plan.ksplit = 1;   // epilogue GEMMs never split
-        u[i].slab_elems = u[i].plan.ksplit > 1 ? (long long)u[i].plan.ksplit * u[i].M * u[i].N : 0;
+        if (i == U_DW1C || i == U_DW1S) {                       // grouped: tiles are counted per column segment
+            long long tb = 0, ts = 0;
+            const long long segs_c[5] = {d.dv, (d.flags & NCX_F_V_MULT) ? d.dv : 0, d.K + 1, d.dz, aemb ? d.A : d.da};
+            const long long segs_s[5] = {d.dv, d.dq, d.dz, d.da, 0};
+            const long long* sg = i == U_DW1C ? segs_c : segs_s;
+            for (int q = 0; q < 5; ++q) { tb += cdiv(H, 128) * cdiv(sg[q], 128); ts += cdiv(H, 64) * cdiv(sg[q], 64); }
+            u[i].plan = plan_from_tiles(tb, ts, u[i].ksteps, H >= 96);
+        } else {
+            u[i].plan = plan_gemm(u[i].form, u[i].M, u[i].N, u[i].ksteps, u[i].allow96);
+        }
+        if (i == U_MAIN || i == U_FWD_L || i == U_DXL) { u[i].plan.ksplit = 1; u[i].plan.sk_wgs = 0; }   // epilogue GEMMs never split
+        {   // experiment hook: NCX_SPLIT_<id>=S forces S aligned k-chunks (0 = no split), NCX_CFG_<id>=0|1 the tile
+            char name[32];
+            snprintf(name, sizeof name, "NCX_SPLIT_%d", i);
+            const char* e = getenv(name);
+            snprintf(name, sizeof name, "NCX_CFG_%d", i);
+            const char* c = getenv(name);
+            if (c && (i != U_MAIN && i != U_FWD_L)) u[i].plan.cfg = atoi(c) ? CFG_128x128 : CFG_64x64;
+            if (e && i != U_MAIN && i != U_FWD_L && i != U_DXL) {
+                int bm0, bn0; cfg_tile(u[i].plan.cfg, bm0, bn0);
+                long long t = 0;
+                if (i == U_DW1C || i == U_DW1S) {
+                    const long long segs_c[5] = {d.dv, (d.flags & NCX_F_V_MULT) ? d.dv : 0, d.K + 1, d.dz, aemb ? d.A : d.da};
+                    const long long segs_s[5] = {d.dv, d.dq, d.dz, d.da, 0};
+                    const long long* sg = i == U_DW1C ? segs_c : segs_s;
+                    for (int q = 0; q < 5; ++q) t += cdiv(H, bm0) * cdiv(sg[q], bn0);
+                } else {
+                    t = cdiv(u[i].M, bm0) * cdiv(u[i].N, bn0);
+                }
+                const int sp = atoi(e);
+                u[i].plan.sk_wgs = sp > 1 ? (int)(t * sp) : 0;
+            }
+        }
+        int bm, bn; cfg_tile(u[i].plan.cfg, bm, bn);
+        u[i].slab_elems = u[i].plan.sk_wgs > 0 ? (long long)u[i].plan.sk_wgs * 2 * bm * bn : 0;
     }
 }
 
@@ -416,37 +478,26 @@ static int run_gemm(int use_id, GemmArgs& a, int form, const GemmPlan& pl, float
 
 static int run_gemm_impl(GemmArgs& a, int form, const GemmPlan& pl, float* slab, size_t slab_bytes,
                          const float* reduce_bias, hipStream_t s) {
-    a.ksplit = pl.ksplit;
-    ReduceArgs ra{};
-    if (pl.ksplit > 1) {
-        const int np = a.mode == MODE_GROUP ? a.nseg : 1;
-        long long total_cols = 0;
-        for (int i = 0; i < np; ++i) total_cols += a.n_cols[i];
-        const long long per_slab = (long long)a.M * total_cols;
-        if ((size_t)(per_slab * pl.ksplit * 4) > slab_bytes) return NCX_E_WORKSPACE;
-        long long c0 = 0;
-        for (int i = 0; i < np; ++i) {
-            ra.r[i].src = slab + c0; ra.r[i].lds = total_cols;
-            ra.r[i].dst = a.out[i]; ra.r[i].ldd = a.ldo[i];
-            ra.r[i].cols = a.n_cols[i]; ra.r[i].col0 = (int)c0;
-            ra.r[i].bias = reduce_bias;
-            a.out[i] = slab + c0; a.ldo[i] = total_cols;
-            c0 += a.n_cols[i];
+    a.ksplit = 1;
+    a.sk_wgs = 0;
+    if (pl.sk_wgs > 0) {
+        int bm, bn; cfg_tile(pl.cfg, bm, bn);
+        if ((size_t)pl.sk_wgs * 2 * bm * bn * 4 > slab_bytes) return NCX_E_WORKSPACE;
+        long long steps = 0;
+        if (a.mode == MODE_GROUP) {
+            steps = cdiv(a.klen[0], GEMM_BK);
+            for (int i = 1; i < a.nseg; ++i) if (cdiv(a.klen[i], GEMM_BK) != steps) return NCX_E_DIMS;
+        } else {
+            for (int i = 0; i < a.nseg; ++i) steps += cdiv(a.klen[i], GEMM_BK);
         }
-        ra.nr = np; ra.rows = a.M; ra.ksplit = pl.ksplit; ra.split_stride = per_slab; ra.total_cols = (int)total_cols;
-        a.split_stride = per_slab;
+        a.sk_wgs = pl.sk_wgs; a.sk_steps = (int)steps; a.sk_slab = slab;
+        a.epi.bias = reduce_bias;                                 // applied by the fix-up kernel
+    } else if (reduce_bias) {
+        a.epi.bias = reduce_bias;
     }
-    int rc;
-    if (form == FORM_NT) rc = run_gemm_nt(a, pl.cfg, s);
-    else if (form == FORM_TN) rc = run_gemm_tn(a, pl.cfg, s);
-    else rc = run_gemm_nn(a, pl.cfg, s);
-    if (rc != 0) return rc;
-    if (pl.ksplit > 1) {
-        const long long n = (long long)ra.rows * ra.total_cols;
-        hipLaunchKernelGGL(k_slab_reduce, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, ra);
-        NCX_HIP_TRY(hipGetLastError());
-    }
-    return 0;
+    if (form == FORM_NT) return run_gemm_nt(a, pl.cfg, s);
+    if (form == FORM_TN) return run_gemm_tn(a, pl.cfg, s);
+    return run_gemm_nn(a, pl.cfg, s);
 }
 
 static void set_dropout(EpiArgs& e, const ncx_dims& d, const ncx_inputs& in, int layer, long long M) {
@@ -525,13 +576,7 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
                       : x_plain(in->a_emb_gt, d.da, d.B, d.da);
         a.b[3] = x_plain(p->w1 + o.a_gt, din, H, d.da); a.klen[3] = d.da;
         a.out[0] = sh; a.ldo[0] = H; a.n_cols[0] = H;
-        GemmPlan pl = u[U_SH].plan;
-        if (pl.ksplit > 1) {
-            rc = run_gemm(U_SH, a, FORM_NT, pl, slab, w.slab_bytes, p->b1, s);
-        } else {
-            a.epi.bias = p->b1;
-            rc = run_gemm(U_SH, a, FORM_NT, pl, slab, w.slab_bytes, nullptr, s);
-        }
+        rc = run_gemm(U_SH, a, FORM_NT, u[U_SH].plan, slab, w.slab_bytes, p->b1, s);
         if (rc) return rc;
     }
     // h1 = drop(relu(Sh[b] + candidate segments))
@@ -618,7 +663,7 @@ int ncx_backward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, 
     auto colsum = [&](const float* x, const float* wgt, int rows, int cols, float* out) -> int {
         const int ch = rows < NCX_COLSUM_CHUNKS * 8 ? (int)cdiv(rows, 8) : NCX_COLSUM_CHUNKS;
         hipLaunchKernelGGL(k_colsum_partial, dim3((unsigned)cdiv(cols, 256), ch), dim3(256), 0, s, x, wgt, rows, cols, partial);
-        hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)cdiv(cols, 256)), dim3(256), 0, s, (const float*)partial, ch, cols, out);
+        hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)cdiv(cols, 8)), dim3(256), 0, s, (const float*)partial, ch, cols, out);
         return (int)hipGetLastError();
     };
     (void)nch;
@@ -769,7 +814,7 @@ int ncx_plan_query(const ncx_dims* d, int32_t gemm_id, int32_t* out6) {
     GemmUse u[U_COUNT];
     list_uses(*d, u);
     out6[0] = u[gemm_id].form; out6[1] = (int32_t)u[gemm_id].M; out6[2] = (int32_t)u[gemm_id].N;
-    out6[3] = (int32_t)u[gemm_id].ksteps; out6[4] = u[gemm_id].plan.cfg; out6[5] = u[gemm_id].plan.ksplit;
+    out6[3] = (int32_t)u[gemm_id].ksteps; out6[4] = u[gemm_id].plan.cfg; out6[5] = u[gemm_id].plan.sk_wgs;
     return NCX_OK;
 }
 

@@ -87,6 +87,9 @@ struct GemmArgs {
     int   tile0[NCX_MAX_SEG + 1];// GROUP: first linear tile id of problem i
     int   mode, nseg, M, ksplit;
     long long split_stride;      // elements between split-K slabs of out (ksplit > 1)
+    int   sk_wgs;                // > 0: stream-K: sk_wgs workgroups share tiles x sk_steps k-step units evenly
+    int   sk_steps;              // k-steps per tile (equal for every tile)
+    float* sk_slab;              // [sk_wgs][2][BM*BN] partial tiles
     EpiArgs epi;
 };
 
@@ -340,25 +343,48 @@ __global__ __launch_bounds__(256, 2) void seg_gemm_kernel(const GemmArgs args) {
     const int li = lane & 15, lk = lane >> 4;
     const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
 
+    const int M = args.M;
+    // ---- stream-K: this workgroup's contiguous range of (tile, k-step) units ----------------------
+    long long sk_u = 0, sk_end = 0;
+    if (args.sk_wgs > 0) {
+        int total_tiles = 0;
+        if (args.mode == MODE_GROUP) total_tiles = args.tile0[args.nseg];
+        else total_tiles = ((M + BM - 1) / BM) * ((args.n_cols[0] + BN - 1) / BN);
+        const long long U = (long long)total_tiles * args.sk_steps;
+        sk_u = U * blockIdx.x / args.sk_wgs;
+        sk_end = U * (blockIdx.x + 1) / args.sk_wgs;
+    }
+    int sk_piece = 0;
+    f32x4 acc[WM][WN];
+  for (;;) {                                     // one iteration per piece (exactly one without stream-K)
+    int prob = 0, tile = blockIdx.x, step_begin, step_end;
+    if (args.sk_wgs > 0) {
+        if (sk_u >= sk_end) break;
+        tile = (int)(sk_u / args.sk_steps);
+        step_begin = (int)(sk_u - (long long)tile * args.sk_steps);
+        const long long left = sk_end - sk_u;
+        step_end = (int)(step_begin + left < args.sk_steps ? step_begin + left : args.sk_steps);
+        sk_u += step_end - step_begin;
+    }
     // ---- which problem / tile -------------------------------------------------------------------
-    int prob = 0, tile = blockIdx.x;
     if (args.mode == MODE_GROUP) {
         while (prob + 1 < args.nseg && tile >= args.tile0[prob + 1]) ++prob;
         tile -= args.tile0[prob];
     }
     const int N = args.n_cols[prob];
-    const int M = args.M;
     const int tiles_n = (N + BN - 1) / BN;
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
 
     // ---- K range of this split ------------------------------------------------------------------
     const int first_seg = args.mode == MODE_GROUP ? prob : 0;
     const int last_seg  = args.mode == MODE_GROUP ? prob + 1 : args.nseg;
-    int total_steps = 0;
-    for (int s = first_seg; s < last_seg; ++s) total_steps += (args.klen[s] + BK - 1) / BK;
     const int z = blockIdx.y;
-    const int step_begin = (int)((long long)total_steps * z / args.ksplit);
-    const int step_end   = (int)((long long)total_steps * (z + 1) / args.ksplit);
+    if (args.sk_wgs <= 0) {
+        int total_steps = 0;
+        for (int s = first_seg; s < last_seg; ++s) total_steps += (args.klen[s] + BK - 1) / BK;
+        step_begin = (int)((long long)total_steps * z / args.ksplit);
+        step_end   = (int)((long long)total_steps * (z + 1) / args.ksplit);
+    }
 
     // cursor: (segment, k position)
     int seg = first_seg, kpos = 0;
@@ -375,7 +401,6 @@ __global__ __launch_bounds__(256, 2) void seg_gemm_kernel(const GemmArgs args) {
     typename Cfg::BLoad lb;
     auto adesc = [&](int s) -> const XDesc& { return args.a[args.mode == MODE_GROUP ? 0 : s]; };
 
-    f32x4 acc[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -562,6 +587,20 @@ __global__ __launch_bounds__(256, 2) void seg_gemm_kernel(const GemmArgs args) {
     }
 
     // ---- epilogue -------------------------------------------------------------------------------
+    if (args.sk_wgs > 0) {
+        // partial tile -> slab slot (whole padded tile, no bounds: padded operands contribute zeros)
+        float* slot = args.sk_slab + ((long long)blockIdx.x * 2 + sk_piece) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    slot[(wm0 + i * 16 + lk * 4 + q) * BN + wn0 + j * 16 + li] = acc[i][j][q];
+        ++sk_piece;
+        __syncthreads();                    // LDS tiles are reused by the next piece
+        continue;
+    }
     float* out = args.out[args.mode == MODE_GROUP ? prob : 0];
     const long long ldo = args.ldo[args.mode == MODE_GROUP ? prob : 0];
     if (args.ksplit > 1) out += (long long)z * args.split_stride;
@@ -579,6 +618,63 @@ __global__ __launch_bounds__(256, 2) void seg_gemm_kernel(const GemmArgs args) {
                     if (!plain) v = apply_epilogue(args.epi, v, r, n, N);
                     out[(long long)r * ldo + n] = v;
                 }
+            }
+        }
+    }
+    break;
+  }   // piece loop
+}
+
+// Stream-K fix-up: tile t = sum of the partial tiles of the workgroups whose unit range overlaps it, in
+// workgroup order (deterministic), + optional bias; scattered to the problem's output with bounds.
+struct FixupArgs {
+    float* out[NCX_MAX_SEG]; long long ldo[NCX_MAX_SEG]; int n_cols[NCX_MAX_SEG]; int tile0[NCX_MAX_SEG + 1];
+    const float* bias;
+    const float* slab;
+    int mode, nseg, M, sk_wgs, sk_steps, total_tiles;
+};
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void streamk_fixup_kernel(const FixupArgs a) {
+    int tile = blockIdx.x, prob = 0;
+    const int t_lin = tile;
+    if (a.mode == MODE_GROUP) {
+        while (prob + 1 < a.nseg && tile >= a.tile0[prob + 1]) ++prob;
+        tile -= a.tile0[prob];
+    }
+    const int N = a.n_cols[prob];
+    const int tiles_n = (N + BN - 1) / BN;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const long long U = (long long)a.total_tiles * a.sk_steps;
+    const long long u0 = (long long)t_lin * a.sk_steps, u1 = u0 + a.sk_steps - 1;
+    auto owner = [&](long long u) {               // workgroup w with start(w) <= u < start(w+1), start(w) = U*w/W
+        int w = (int)((u * a.sk_wgs) / U);
+        while (w + 1 < a.sk_wgs && U * (w + 1) / a.sk_wgs <= u) ++w;
+        while (w > 0 && U * w / a.sk_wgs > u) --w;
+        return w;
+    };
+    const int w_lo = owner(u0), w_hi = owner(u1);
+    float* out = a.out[prob];
+    const long long ldo = a.ldo[prob];
+    constexpr int E = BM * BN / 1024;                 // float4 per thread
+    f32x4 s[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int w = w_lo; w <= w_hi; ++w) {             // workgroup order: deterministic
+        const long long st = U * w / a.sk_wgs;
+        const int slot = (int)(st / a.sk_steps) == t_lin ? 0 : 1;
+        const float* src = a.slab + ((long long)w * 2 + slot) * (BM * BN) + threadIdx.x * 4;
+#pragma unroll
+        for (int i = 0; i < E; ++i) s[i] += *(const f32x4*)(src + i * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < E; ++i) {
+        const int e = i * 1024 + threadIdx.x * 4;
+        const int gr = m0 + e / BN, c = e % BN;
+        if (gr < a.M) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int gc = n0 + c + j;
+                if (gc < N) out[(long long)gr * ldo + gc] = s[i][j] + (a.bias ? a.bias[gc] : 0.f);
             }
         }
     }
@@ -608,9 +704,27 @@ static inline hipError_t launch_seg_gemm(GemmArgs& args, hipStream_t stream) {
         attr_set = true;
     }
     if (args.ksplit < 1) args.ksplit = 1;
+    if (args.sk_wgs > 0) {
+        args.ksplit = 1;
+        hipLaunchKernelGGL((seg_gemm_kernel<BM, BN, A_COLK, B_COLK>), dim3(args.sk_wgs), dim3(256), Cfg::LDS_BYTES, stream, args);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        FixupArgs f{};
+        for (int i = 0; i < NCX_MAX_SEG; ++i) { f.out[i] = args.out[i]; f.ldo[i] = args.ldo[i]; f.n_cols[i] = args.n_cols[i]; f.tile0[i] = args.tile0[i]; }
+        f.tile0[NCX_MAX_SEG] = args.tile0[NCX_MAX_SEG];
+        f.bias = args.epi.bias; f.slab = args.sk_slab; f.mode = args.mode; f.nseg = args.nseg; f.M = args.M;
+        f.sk_wgs = args.sk_wgs; f.sk_steps = args.sk_steps; f.total_tiles = tiles;
+        hipLaunchKernelGGL((streamk_fixup_kernel<BM, BN>), dim3(tiles), dim3(256), 0, stream, f);
+        return hipGetLastError();
+    }
     dim3 grid(tiles, args.ksplit, 1);
     hipLaunchKernelGGL((seg_gemm_kernel<BM, BN, A_COLK, B_COLK>), grid, dim3(256), Cfg::LDS_BYTES, stream, args);
     return hipGetLastError();
+}
+
+// Tile geometry of a config, for the planner.
+static inline void cfg_tile(int cfg, int& bm, int& bn) {
+    bm = cfg == 1 ? 128 : cfg == 2 ? 96 : 64; bn = cfg == 0 ? 64 : 128;
 }
 
 #endif  // __HIPCC__

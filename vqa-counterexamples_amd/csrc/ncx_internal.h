@@ -33,7 +33,7 @@ static inline SegOffsets seg_offsets(const ncx_dims& d) {
 }
 
 // Split-K plan of one GEMM: tile config + number of K splits (slabs reduced by k_slab_reduce).
-struct GemmPlan { int cfg; int ksplit; };
+struct GemmPlan { int cfg; int ksplit; int sk_wgs; };   // sk_wgs > 0: stream-K over that many workgroups
 GemmPlan plan_gemm(int form, long long M, long long N, long long ksteps, bool allow_96);
 
 // Workspace partition (byte offsets from a 256-byte aligned base).  Saved-for-backward part first.
@@ -53,7 +53,7 @@ struct WsLayout {
     size_t slab_bytes;
     size_t total;
 };
-constexpr int NCX_COLSUM_CHUNKS = 128;
+constexpr int NCX_COLSUM_CHUNKS = 256;
 WsLayout ws_layout(const ncx_dims& d);
 
 }  // namespace ncx
