@@ -306,43 +306,41 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
 
 // Split planning.  A problem whose whole tiles cannot fill the chip is split along K into S aligned chunks and
-// run as W = tiles*S workgroups through the stream-K path (unit ranges of W = tiles*S workgroups coincide with
-// the chunks, so workgroups working on the same chunk of different tiles share their operand rows in L2 --
-// unaligned stream-K ranges lose that sharing and ran 1.3x slower).  S minimises a makespan estimate:
-// workgroups per busiest CU x k-steps per workgroup / MFMA efficiency at that residency.
-static int choose_split(long long tiles, long long ksteps, int occ) {
-    static const double eff[4] = {1.0, 0.60, 0.85, 0.90};
-    double best = 1e30; int best_s = 1;
-    const long long smax = ksteps / 8 > 1 ? ksteps / 8 : 1;
-    for (long long sp = 1; sp <= smax && sp <= 64; ++sp) {
-        const long long wgs = tiles * sp;
-        const double steps = (double)cdiv(ksteps, sp) + 4.0;            // + pipeline prologue/epilogue
-        long long per_cu = cdiv(wgs, 256);
-        double t;
-        if (per_cu <= occ) t = per_cu * steps / eff[per_cu];
-        else t = (double)cdiv(wgs, 256 * occ) * occ * steps / eff[occ];
-        t += 0.02 * sp * steps;                                          // partial-tile traffic + fix-up
-        if (t < best - 1e-9) { best = t; best_s = (int)sp; }
+// run as W = tiles*S equal workgroups through the stream-K path (W = tiles*S makes the unit ranges coincide with
+// the chunks, so workgroups on the same chunk of different tiles share operand rows in L2; unaligned ranges lost
+// that sharing and ran 1.3x slower).  Equal workgroups execute in rounds of `slots` = CUs x resident
+// workgroups per CU, so S is chosen to fill whole rounds (1648 workgroups on 512 slots = 3.2 rounds cost 4).
+int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else { (void)hipGetLastError(); n = 256; }
     }
-    return best_s;
+    return n;
 }
 
-// tiles_big / tiles_small: output tiles with 128x128 / 64x64 blocks; ksteps: 32-deep reduction steps per tile.
-static GemmPlan plan_from_tiles(long long tiles_big, long long tiles_small, long long ksteps, bool big_ok) {
+// Measured (DW1C on 512 slots, 412 tiles x 384 k-steps): S = 4/5/6/7/9/12/16/24/32 -> 0.541/0.538/0.521/0.513/
+// 0.486/0.486/0.486/0.508/0.525 ms: aim for >= 6 rounds of workgroups but keep >= 24 k-steps in each.
+static int choose_split(long long tiles, long long ksteps, long long slots) {
+    if (tiles >= 4 * slots) return 1;
+    long long sp = cdiv(6 * slots, tiles);
+    const long long smax = ksteps / 24 > 1 ? ksteps / 24 : 1;
+    if (sp > smax) sp = smax;
+    return (int)(sp < 1 ? 1 : sp);
+}
+
+// tiles_small: output tiles with 64x64 blocks; ksteps: 32-deep reduction steps per tile.
+static GemmPlan plan_from_tiles(int form, long long tiles_big, long long tiles_small, long long ksteps, bool big_ok) {
     GemmPlan p; p.ksplit = 1; p.sk_wgs = 0;
     if (big_ok && tiles_big >= 192 && ksteps >= 64) { p.cfg = CFG_128x128; return p; }
     // Measured on MI355X (DW1C, 104 big / 412 small tiles x 384 k-steps): the 128x128 TN/NT instantiations spill
-    // (233 VGPRs) and reach 0.75-0.81 ms at any split, the spill-free 64x64 tile 0.57 ms at 4 chunks.  Until the
-    // big-tile kernel is slimmed down, split problems use 64x64 tiles with ~6 resident workgroups' worth of
-    // work per CU.
-    (void)big_ok;
+    // (233 VGPRs) and reach 0.75-0.81 ms at any split, the spill-free 64x64 tile 0.54 ms: split problems use it.
     p.cfg = CFG_64x64;
-    const long long tiles = tiles_small;
-    long long sp = cdiv(1536, tiles);
-    const long long smax = ksteps / 8 > 1 ? ksteps / 8 : 1;
-    if (sp > smax) sp = smax;
-    if (tiles >= 1024) sp = 1;
-    if (sp > 1) p.sk_wgs = (int)(tiles * sp);
+    const int occ = form == FORM_NT ? occupancy_nt(CFG_64x64) : form == FORM_TN ? occupancy_tn(CFG_64x64) : occupancy_nn(CFG_64x64);
+    const long long slots = (long long)occ * num_cus();
+    const int sp = choose_split(tiles_small, ksteps, slots);
+    if (sp > 1) p.sk_wgs = (int)(tiles_small * sp);
     return p;
 }
 
@@ -352,7 +350,7 @@ GemmPlan plan_gemm(int form, long long M, long long N, long long ksteps, bool al
         GemmPlan p; p.cfg = CFG_96x128; p.ksplit = 1; p.sk_wgs = 0; return p;
     }
     const bool big_ok = M >= 96 && N >= 96;
-    return plan_from_tiles(cdiv(M, 128) * cdiv(N, 128), cdiv(M, 64) * cdiv(N, 64), ksteps, big_ok);
+    return plan_from_tiles(form, cdiv(M, 128) * cdiv(N, 128), cdiv(M, 64) * cdiv(N, 64), ksteps, big_ok);
 }
 
 // The GEMMs of one step, so that ws_layout and forward/backward agree on split-K slab sizes.
@@ -386,7 +384,7 @@ static void list_uses(const ncx_dims& d, GemmUse* u) {
             const long long segs_s[5] = {d.dv, d.dq, d.dz, d.da, 0};
             const long long* sg = i == U_DW1C ? segs_c : segs_s;
             for (int q = 0; q < 5; ++q) { tb += cdiv(H, 128) * cdiv(sg[q], 128); ts += cdiv(H, 64) * cdiv(sg[q], 64); }
-            u[i].plan = plan_from_tiles(tb, ts, u[i].ksteps, H >= 96);
+            u[i].plan = plan_from_tiles(FORM_TN, tb, ts, u[i].ksteps, H >= 96);
         } else {
             u[i].plan = plan_gemm(u[i].form, u[i].M, u[i].N, u[i].ksteps, u[i].allow96);
         }
@@ -397,7 +395,7 @@ static void list_uses(const ncx_dims& d, GemmUse* u) {
             const char* e = getenv(name);
             snprintf(name, sizeof name, "NCX_CFG_%d", i);
             const char* c = getenv(name);
-            if (c && (i != U_MAIN && i != U_FWD_L)) u[i].plan.cfg = atoi(c) ? CFG_128x128 : CFG_64x64;
+            if (c) u[i].plan.cfg = atoi(c);       // 0 64x64, 1 128x128, 2 96x128 (NT only), 3 96x64 (NT only)
             if (e && i != U_MAIN && i != U_FWD_L && i != U_DXL) {
                 int bm0, bn0; cfg_tile(u[i].plan.cfg, bm0, bn0);
                 long long t = 0;

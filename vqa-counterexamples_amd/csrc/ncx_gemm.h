@@ -16,7 +16,7 @@
 //
 // Operand forms.  An operand tile lives in LDS as a row-major copy of an x sub-block and is either
 //   "col-is-k": the reduction index runs along the COLUMNS of x  (tile [rows=out index][32 k], pitch 34)
-//   "row-is-k": the reduction index runs along the ROWS of x     (tile [32 k][cols=out index], pitch = 16 mod 32)
+//   "row-is-k": the reduction index runs along the ROWS of x     (tile [32 k][cols=out index], pitch = 8 mod 32)
 // so NT (forward: X.W^T), TN (weight grad: D^T.X) and NN (input grad: D.W) products all use the same
 // loader (global loads are always 16 B along the contiguous c axis) and the same conflict-free
 // ds_read_b32 fragment reads for v_mfma_f32_16x16x4_f32.
@@ -100,7 +100,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__host__ __device__ constexpr int pitch_rowk(int c) { return ((c - 16 + 31) / 32) * 32 + 16; }  // >= c, = 16 mod 32
+// Row-is-k LDS pitch: lane groups lk = 0..3 read k-rows 8t + 2*lk + e, i.e. the two groups of a 32-lane half sit
+// TWO rows apart, so 2*pitch must be 16 mod 32: pitch = 8 mod 32 (>= c, multiple of 4 for ds_write_b128).
+__host__ __device__ constexpr int pitch_rowk(int c) { return ((c - 8 + 31) / 32) * 32 + 8; }
 
 // 4 consecutive columns of one row (always a valid row pointer; cols >= 4).  The load is UNCONDITIONAL and
 // identical for interior and edge tiles: the 16-byte window is slid left to stay inside [0, cols)
@@ -244,6 +246,9 @@ struct OpLoader {
     // KIND: COLK operands have their row pointers resolved in setup(), so X_GATHER == X_PLAIN there.
     template <int KIND>
     __device__ __forceinline__ void issue_fast(const XDesc& d, int k, int tid) {
+#ifdef NCX_ABLATE_LOADS          // timing experiment only: keep the registers of the first tile
+        return;
+#endif
         if (COLK) {
             const int c = k + 4 * (tid & 7);
 #pragma unroll
@@ -272,6 +277,9 @@ struct OpLoader {
     }
     template <int KIND>
     __device__ __forceinline__ void store_fast(float* lds, int tid) const {
+#ifdef NCX_ABLATE_STORES         // timing experiment only
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int ri = COLK ? i : 0;
@@ -476,32 +484,46 @@ __global__ __launch_bounds__(256, 2) void seg_gemm_kernel(const GemmArgs args) {
             const float* pa = lds_a + buf * Cfg::A_ELEMS;
             const float* pb = lds_b + buf * Cfg::B_ELEMS;
             f32x2 af0[WM], bf0[WN], af1[WM], bf1[WN];
-            la.template issue_fast<AK>(da, kpos, tid);
-            lb.template issue_fast<BKD>(db, kpos, tid);
             read_frags(pa, pb, 0, af0, bf0);
             __builtin_amdgcn_sched_barrier(0);
+            // sub-step 0: its MFMAs carry the global loads of tile t+1 (one address add + one load per gap) and
+            // the fragment reads of sub-step 1 -- with one wave per SIMD only what sits BETWEEN two MFMAs is hidden
+            la.template issue_fast<AK>(da, kpos, tid);
+            lb.template issue_fast<BKD>(db, kpos, tid);
             read_frags(pa, pb, 1, af1, bf1);
             mfma_frags(af0, bf0);
-            __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
+#pragma unroll
+            for (int q = 0; q < NMFMA; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);     // VALU (address arithmetic)
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
+            }
             __builtin_amdgcn_sched_barrier(0);
             read_frags(pa, pb, 2, af0, bf0);
             mfma_frags(af1, bf1);
-            __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
+#pragma unroll
+            for (int q = 0; q < NMFMA; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             read_frags(pa, pb, 3, af1, bf1);
             mfma_frags(af0, bf0);
-            __builtin_amdgcn_sched_group_barrier(0x100, NREADS, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
+#pragma unroll
+            for (int q = 0; q < NMFMA; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
+            // sub-step 3: transform (exp2 / product) + ds_write of tile t+1 in the MFMA shadows
             la.template store_fast<AK>(lds_a + (buf ^ 1) * Cfg::A_ELEMS, tid);
             lb.template store_fast<BKD>(lds_b + (buf ^ 1) * Cfg::B_ELEMS, tid);
             mfma_frags(af1, bf1);
 #pragma unroll
             for (int q = 0; q < NMFMA; ++q) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);     // up to 4 VALU in its shadow
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);     // up to 3 VALU in its shadow
                 __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);     // up to 1 ds_write
             }
             __syncthreads();
@@ -722,9 +744,23 @@ static inline hipError_t launch_seg_gemm(GemmArgs& args, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// Resident workgroups per CU of an instantiation (registers / LDS), for the planner; 2 when no device is present.
+template <int BM, int BN, bool A_COLK, bool B_COLK>
+static inline int seg_gemm_occupancy() {
+    typedef GemmCfg<BM, BN, A_COLK, B_COLK> Cfg;
+    int n = 0;
+    (void)hipFuncSetAttribute((const void*)seg_gemm_kernel<BM, BN, A_COLK, B_COLK>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, seg_gemm_kernel<BM, BN, A_COLK, B_COLK>, 256, Cfg::LDS_BYTES) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        n = 2;
+    }
+    return n;
+}
+
 // Tile geometry of a config, for the planner.
 static inline void cfg_tile(int cfg, int& bm, int& bn) {
-    bm = cfg == 1 ? 128 : cfg == 2 ? 96 : 64; bn = cfg == 0 ? 64 : 128;
+    bm = cfg == 1 ? 128 : (cfg == 2 || cfg == 3) ? 96 : 64; bn = (cfg == 0 || cfg == 3) ? 64 : 128;
 }
 
 #endif  // __HIPCC__

@@ -11,8 +11,21 @@ int run_gemm_nt(GemmArgs& a, int cfg, hipStream_t s) {
     switch (cfg) {
     case CFG_128x128: return (int)launch_seg_gemm<128, 128, true, true>(a, s);
     case CFG_96x128:  return (int)launch_seg_gemm<96, 128, true, true>(a, s);
+    case CFG_96x64:   return (int)launch_seg_gemm<96, 64, true, true>(a, s);
     default:          return (int)launch_seg_gemm<64, 64, true, true>(a, s);
     }
+}
+int occupancy_nt(int cfg) {
+    static int occ[4] = {0, 0, 0, 0};
+    if (!occ[cfg & 3]) {
+        switch (cfg) {
+        case CFG_128x128: occ[1] = seg_gemm_occupancy<128, 128, true, true>(); break;
+        case CFG_96x128:  occ[2] = seg_gemm_occupancy<96, 128, true, true>(); break;
+        case CFG_96x64:   occ[3] = seg_gemm_occupancy<96, 64, true, true>(); break;
+        default:          occ[0] = seg_gemm_occupancy<64, 64, true, true>(); break;
+        }
+    }
+    return occ[cfg & 3];
 }
 #elif NCX_FORM == 1
 // C[M,N] = D[k,M]^T . X[k,N]                (weight gradients; both operands row-is-k)
@@ -22,6 +35,12 @@ int run_gemm_tn(GemmArgs& a, int cfg, hipStream_t s) {
     default:          return (int)launch_seg_gemm<64, 64, false, false>(a, s);
     }
 }
+int occupancy_tn(int cfg) {
+    static int occ[2] = {0, 0};
+    const int i = cfg == CFG_128x128;
+    if (!occ[i]) occ[i] = i ? seg_gemm_occupancy<128, 128, false, false>() : seg_gemm_occupancy<64, 64, false, false>();
+    return occ[i];
+}
 #else
 // C[M,N] = D[M,k] . W[k,N]                  (input gradients; A col-is-k, B row-is-k)
 int run_gemm_nn(GemmArgs& a, int cfg, hipStream_t s) {
@@ -29,6 +48,12 @@ int run_gemm_nn(GemmArgs& a, int cfg, hipStream_t s) {
     case CFG_128x128: return (int)launch_seg_gemm<128, 128, true, false>(a, s);
     default:          return (int)launch_seg_gemm<64, 64, true, false>(a, s);
     }
+}
+int occupancy_nn(int cfg) {
+    static int occ[2] = {0, 0};
+    const int i = cfg == CFG_128x128;
+    if (!occ[i]) occ[i] = i ? seg_gemm_occupancy<128, 128, true, false>() : seg_gemm_occupancy<64, 64, true, false>();
+    return occ[i];
 }
 #endif
 

@@ -5,12 +5,15 @@
 
 namespace ncx {
 
-enum TileCfg : int { CFG_64x64 = 0, CFG_128x128 = 1, CFG_96x128 = 2 };
+enum TileCfg : int { CFG_64x64 = 0, CFG_128x128 = 1, CFG_96x128 = 2, CFG_96x64 = 3 };
 enum GemmForm : int { FORM_NT = 0, FORM_TN = 1, FORM_NN = 2 };
 
 int run_gemm_nt(GemmArgs& a, int cfg, hipStream_t s);
 int run_gemm_tn(GemmArgs& a, int cfg, hipStream_t s);
 int run_gemm_nn(GemmArgs& a, int cfg, hipStream_t s);
+int occupancy_nt(int cfg);
+int occupancy_tn(int cfg);
+int occupancy_nn(int cfg);
 
 // Column offsets of the reference's concat (vqa/models/cx.py:309-320) == layout of linear_1.weight.
 struct SegOffsets {
@@ -35,6 +38,7 @@ static inline SegOffsets seg_offsets(const ncx_dims& d) {
 // Split-K plan of one GEMM: tile config + number of K splits (slabs reduced by k_slab_reduce).
 struct GemmPlan { int cfg; int ksplit; int sk_wgs; };   // sk_wgs > 0: stream-K over that many workgroups
 GemmPlan plan_gemm(int form, long long M, long long N, long long ksteps, bool allow_96);
+int num_cus();
 
 // Workspace partition (byte offsets from a 256-byte aligned base).  Saved-for-backward part first.
 struct WsLayout {
