@@ -336,11 +336,13 @@ static GemmPlan plan_from_tiles(int form, long long tiles_big, long long tiles_s
     if (big_ok && tiles_big >= 192 && ksteps >= 64) { p.cfg = CFG_128x128; return p; }
     // Measured on MI355X (DW1C, 104 big / 412 small tiles x 384 k-steps): the 128x128 TN/NT instantiations spill
     // (233 VGPRs) and reach 0.75-0.81 ms at any split, the spill-free 64x64 tile 0.54 ms: split problems use it.
-    p.cfg = CFG_64x64;
-    const int occ = form == FORM_NT ? occupancy_nt(CFG_64x64) : form == FORM_TN ? occupancy_tn(CFG_64x64) : occupancy_nn(CFG_64x64);
+    const char* force_big = getenv("NCX_SPLIT_BIG");
+    p.cfg = (force_big && atoi(force_big) && big_ok) ? CFG_128x128 : CFG_64x64;
+    const long long tiles = p.cfg == CFG_128x128 ? tiles_big : tiles_small;
+    const int occ = form == FORM_NT ? occupancy_nt(p.cfg) : form == FORM_TN ? occupancy_tn(p.cfg) : occupancy_nn(p.cfg);
     const long long slots = (long long)occ * num_cus();
-    const int sp = choose_split(tiles_small, ksteps, slots);
-    if (sp > 1) p.sk_wgs = (int)(tiles_small * sp);
+    const int sp = choose_split(tiles, ksteps, slots);
+    if (sp > 1) p.sk_wgs = (int)(tiles * sp);
     return p;
 }
 

@@ -100,9 +100,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Row-is-k LDS pitch: lane groups lk = 0..3 read k-rows 8t + 2*lk + e, i.e. the two groups of a 32-lane half sit
-// TWO rows apart, so 2*pitch must be 16 mod 32: pitch = 8 mod 32 (>= c, multiple of 4 for ds_write_b128).
-__host__ __device__ constexpr int pitch_rowk(int c) { return ((c - 8 + 31) / 32) * 32 + 8; }
+// Row-is-k LDS pitch.  Lane group lk reads k-rows 8t + 2*lk + e, so the two groups of a 32-lane half sit TWO
+// rows apart.  With the interleaved block mapping (below) a lane reads EXT/32 consecutive floats:
+//   ds_read_b128 (EXT = 128): 16 lanes cover all 64 banks; the hardware's mixed 16-lane groups stay disjoint
+//                 when 2*pitch = 0 mod 64  -> pitch = 128 (no padding)
+//   ds_read_b64  (EXT = 64):  a 32-lane half = two 128-byte runs two rows apart -> 2*pitch = 32 mod 64 -> pitch = 80
+//   ds_read_b32  (other EXT): 2*pitch = 16 mod 32 -> pitch = 8 mod 32
+__host__ __device__ constexpr int pitch_rowk(int c) {
+    return c == 128 ? 128 : c == 64 ? 80 : ((c - 8 + 31) / 32) * 32 + 8;
+}
 
 // 4 consecutive columns of one row (always a valid row pointer; cols >= 4).  The load is UNCONDITIONAL and
 // identical for interior and edge tiles: the 16-byte window is slid left to stay inside [0, cols)
@@ -338,8 +344,10 @@ __device__ __forceinline__ float apply_epilogue(const EpiArgs& e, float v, int r
     return v;
 }
 
+// Big tiles get the whole 512-entry register file (one workgroup per CU): at 2 waves per SIMD the 128x128 and
+// 96x128 instantiations spill 90-260 VGPRs.
 template <int BM, int BN, bool A_COLK, bool B_COLK>
-__global__ __launch_bounds__(256, 2) void seg_gemm_kernel(const GemmArgs args) {
+__global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_kernel(const GemmArgs args) {
     typedef GemmCfg<BM, BN, A_COLK, B_COLK> Cfg;
     constexpr int BK = Cfg::BK, PA = Cfg::PA, PB = Cfg::PB, WM = Cfg::WM, WN = Cfg::WN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -414,49 +422,52 @@ __global__ __launch_bounds__(256, 2) void seg_gemm_kernel(const GemmArgs args) {
 #pragma unroll
         for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // k order inside a 32-deep step: MFMA (t, e) takes k = 8t + 2*lk + e from lane group lk, for BOTH operands
-    // (any bijection works as long as A and B agree).  A col-is-k tile then serves two MFMAs per ds_read_b64
-    // (pitch 36: 36*i mod 64 hits 16 distinct multiples of 4, + 2*lk + e: conflict-free over a 32-lane half).
-    auto compute_range = [&](int buf, int t0, int t1) {
-        const float* pa = lds_a + buf * Cfg::A_ELEMS;
-        const float* pb = lds_b + buf * Cfg::B_ELEMS;
-#pragma unroll
-        for (int t = t0; t < t1; ++t) {
-            f32x2 af[WM], bf[WN];
-            const int kk = t * 8 + 2 * lk;
-#pragma unroll
-            for (int i = 0; i < WM; ++i) {
-                if (A_COLK) af[i] = *(const f32x2*)(pa + (wm0 + i * 16 + li) * PA + kk);
-                else af[i] = f32x2{pa[kk * PA + wm0 + i * 16 + li], pa[(kk + 1) * PA + wm0 + i * 16 + li]};
-            }
-#pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                if (B_COLK) bf[j] = *(const f32x2*)(pb + (wn0 + j * 16 + li) * PB + kk);
-                else bf[j] = f32x2{pb[kk * PB + wn0 + j * 16 + li], pb[(kk + 1) * PB + wn0 + j * 16 + li]};
-            }
-#pragma unroll
-            for (int e = 0; e < 2; ++e)
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
-        }
-    };
-    auto compute = [&](int buf) { compute_range(buf, 0, BK / 8); };
+
+    // Interleaved block mapping for row-is-k operands: MFMA block q of this wave owns tile rows/cols
+    // {w0 + W*i + q : i = 0..15} (W = blocks per wave), so ONE ds_read_b128 / _b64 per k-row feeds all W blocks
+    // (16 instead of 64 LDS reads per k-step on the 128x128 tile) and a lane ends up with W consecutive output
+    // columns.  Col-is-k operands keep contiguous 16-row blocks (one ds_read_b64 per block and k-pair).
+    constexpr bool A_IL = !A_COLK && (WM == 4 || WM == 2);
+    constexpr bool B_IL = !B_COLK && (WN == 4 || WN == 2);
+    auto trow = [&](int qa, int r) { return A_IL ? wm0 + WM * r + qa : wm0 + 16 * qa + r; };   // tile-local row
+    auto tcol = [&](int qb, int c) { return B_IL ? wn0 + WN * c + qb : wn0 + 16 * qb + c; };   // tile-local col
 
     // LDS -> register fragments of sub-step t (8 k-values: two MFMAs per accumulator)
     auto read_frags = [&](const float* pa, const float* pb, int t, f32x2 (&af)[WM], f32x2 (&bf)[WN]) {
         const int kk = t * 8 + 2 * lk;
+        if (A_COLK) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i) {
-            if (A_COLK) af[i] = *(const f32x2*)(pa + (wm0 + i * 16 + li) * PA + kk);
-            else af[i] = f32x2{pa[kk * PA + wm0 + i * 16 + li], pa[(kk + 1) * PA + wm0 + i * 16 + li]};
+            for (int i = 0; i < WM; ++i) af[i] = *(const f32x2*)(pa + (wm0 + i * 16 + li) * PA + kk);
+        } else if (A_IL) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (WM == 4) { const f32x4 v = *(const f32x4*)(pa + (kk + e) * PA + wm0 + 4 * li);
+#pragma unroll
+                               for (int i = 0; i < WM; ++i) af[i][e] = v[i]; }
+                else         { const f32x2 v = *(const f32x2*)(pa + (kk + e) * PA + wm0 + 2 * li);
+#pragma unroll
+                               for (int i = 0; i < WM; ++i) af[i][e] = v[i & 1]; }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < WM; ++i) af[i] = f32x2{pa[kk * PA + wm0 + i * 16 + li], pa[(kk + 1) * PA + wm0 + i * 16 + li]};
         }
+        if (B_COLK) {
 #pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            if (B_COLK) bf[j] = *(const f32x2*)(pb + (wn0 + j * 16 + li) * PB + kk);
-            else bf[j] = f32x2{pb[kk * PB + wn0 + j * 16 + li], pb[(kk + 1) * PB + wn0 + j * 16 + li]};
+            for (int j = 0; j < WN; ++j) bf[j] = *(const f32x2*)(pb + (wn0 + j * 16 + li) * PB + kk);
+        } else if (B_IL) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (WN == 4) { const f32x4 v = *(const f32x4*)(pb + (kk + e) * PB + wn0 + 4 * li);
+#pragma unroll
+                               for (int j = 0; j < WN; ++j) bf[j][e] = v[j]; }
+                else         { const f32x2 v = *(const f32x2*)(pb + (kk + e) * PB + wn0 + 2 * li);
+#pragma unroll
+                               for (int j = 0; j < WN; ++j) bf[j][e] = v[j & 1]; }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bf[j] = f32x2{pb[kk * PB + wn0 + j * 16 + li], pb[(kk + 1) * PB + wn0 + j * 16 + li]};
         }
     };
     auto mfma_frags = [&](const f32x2 (&af)[WM], const f32x2 (&bf)[WN]) {
@@ -468,7 +479,21 @@ __global__ __launch_bounds__(256, 2) void seg_gemm_kernel(const GemmArgs args) {
                 for (int j = 0; j < WN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
     };
-    constexpr int NREADS = (A_COLK ? WM : 2 * WM) + (B_COLK ? WN : 2 * WN);   // ds_read instructions per sub-step
+    // k order inside a 32-deep step: MFMA (t, e) takes k = 8t + 2*lk + e from lane group lk, for BOTH operands
+    // (any bijection works as long as A and B agree).  A col-is-k tile then serves two MFMAs per ds_read_b64
+    // (pitch 36: 36*i mod 64 hits 16 distinct multiples of 4, + 2*lk + e: conflict-free over a 32-lane half).
+    auto compute_range = [&](int buf, int t0, int t1) {
+        const float* pa = lds_a + buf * Cfg::A_ELEMS;
+        const float* pb = lds_b + buf * Cfg::B_ELEMS;
+#pragma unroll
+        for (int t = t0; t < t1; ++t) {
+            f32x2 af[WM], bf[WN];
+            read_frags(pa, pb, t, af, bf);
+            mfma_frags(af, bf);
+        }
+    };
+    auto compute = [&](int buf) { compute_range(buf, 0, BK / 8); };
+    constexpr int NREADS = (A_COLK ? WM : A_IL ? 2 : 2 * WM) + (B_COLK ? WN : B_IL ? 2 : 2 * WN);   // ds_read instructions per sub-step
     constexpr int NMFMA = 2 * WM * WN;                                          // MFMAs per sub-step
 
     // One interior k-step with compile-time operand kinds.  Hand-pinned software pipeline (one wave per SIMD
@@ -615,10 +640,10 @@ __global__ __launch_bounds__(256, 2) void seg_gemm_kernel(const GemmArgs args) {
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int j = 0; j < WN; ++j)
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    slot[(wm0 + i * 16 + lk * 4 + q) * BN + wn0 + j * 16 + li] = acc[i][j][q];
+                for (int j = 0; j < WN; ++j)
+                    slot[trow(i, lk * 4 + q) * BN + tcol(j, li)] = acc[i][j][q];
         ++sk_piece;
         __syncthreads();                    // LDS tiles are reused by the next piece
         continue;
@@ -631,10 +656,10 @@ __global__ __launch_bounds__(256, 2) void seg_gemm_kernel(const GemmArgs args) {
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
-            const int n = n0 + wn0 + j * 16 + li;
+            const int n = n0 + tcol(j, li);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int r = m0 + wm0 + i * 16 + lk * 4 + q;
+                const int r = m0 + trow(i, lk * 4 + q);
                 if (r < M && n < N) {
                     float v = acc[i][j][q];
                     if (!plain) v = apply_epilogue(args.epi, v, r, n, N);
