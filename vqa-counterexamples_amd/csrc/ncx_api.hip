@@ -230,12 +230,13 @@ __global__ __launch_bounds__(256) void k_rowgroup_sum(const float* __restrict__ 
     dsh[i] = s;
 }
 
-// dst[aid[b]][:] += src[b][:], deterministically: the first occurrence of an id owns the row and adds
-// every duplicate in batch order (cx.py:280 backward: embedding scatter-add).  Ownership test and the
-// duplicate set (a bitmap in LDS, order-free to build, scanned in increasing order) are block-parallel.
+// dggt[n][a] = sum over {b : aid[b] == a} of dsh[b][n]   (dggt [H][A] pre-zeroed).  One block per triplet; the first
+// occurrence of an answer id owns column a and adds its duplicates in batch order -> deterministic, no atomics on
+// floats.  Backward of the a_emb_gt lookup (cx.py:280) in re-associated form:
+//   dE += S^T (dSh . W1[:, a_emb_gt]) = (S^T dSh) . W1[:, a_emb_gt],  S = one-hot(aid)  -> a second pair of the dE GEMM.
 constexpr int NCX_SCATTER_MAX_B = 32768;
-__global__ __launch_bounds__(256) void k_scatter_rows_dedup(const float* __restrict__ src, const int* __restrict__ aid,
-                                                            int B, int W, float* __restrict__ dst) {
+__global__ __launch_bounds__(256) void k_scatter_dsh_by_answer(const float* __restrict__ dsh, const int* __restrict__ aid,
+                                                               int B, int H, int A, float* __restrict__ dggt) {
     __shared__ unsigned bits[NCX_SCATTER_MAX_B / 32];
     const int b = blockIdx.x;
     const int id = aid[b];
@@ -248,17 +249,17 @@ __global__ __launch_bounds__(256) void k_scatter_rows_dedup(const float* __restr
     for (int j = b + threadIdx.x; j < B; j += 256)
         if (aid[j] == id) atomicOr(&bits[j >> 5], 1u << (j & 31));
     __syncthreads();
-    for (int c = threadIdx.x; c < W; c += 256) {
-        float s = dst[(long long)id * W + c];
+    for (int n = threadIdx.x; n < H; n += 256) {
+        float s = 0.f;
         for (int w = b >> 5; w < nw; ++w) {
             unsigned m = bits[w];
             while (m) {
                 const int j = (w << 5) + __ffs(m) - 1;
                 m &= m - 1;
-                s += src[(long long)j * W + c];
+                s += dsh[(long long)j * H + n];
             }
         }
-        dst[(long long)id * W + c] = s;
+        dggt[(long long)n * A + id] = s;
     }
 }
 
@@ -374,9 +375,9 @@ static void list_uses(const ncx_dims& d, GemmUse* u) {
     u[U_FWD_L] = {FORM_NT, M, H, ks(H), true};
     u[U_DW1C]  = {FORM_TN, H, cand_cols, ks(M), false};
     u[U_DW1S]  = {FORM_TN, H, sh_cols, ks(d.B), false};
-    u[U_DE]    = {FORM_TN, d.A, d.da, ks(H), false};
+    u[U_DE]    = {FORM_TN, d.A, d.da, 2 * ks(H), false};
     u[U_DW1AK] = {FORM_NN, H, d.da, ks(d.A), false};
-    u[U_DAGT]  = {FORM_NN, d.B, d.da, ks(H), false};
+    u[U_DAGT]  = {FORM_NN, 1, 1, 1, false};                 // (folded into U_DE)
     u[U_DWL]   = {FORM_TN, H, H, ks(M), false};
     u[U_DXL]   = {FORM_NN, M, H, ks(H), false};
     for (int i = 0; i < U_COUNT; ++i) {
@@ -433,7 +434,7 @@ WsLayout ws_layout(const ncx_dims& d) {
     w.dpre[1] = d.L >= 2 ? take(M * H * 4) : 0;
     w.dsh = take((size_t)d.B * H * 4);
     w.dgt = take(H * d.A * 4);
-    w.dagt = take((size_t)d.B * d.da * 4);
+    w.dagt = take(H * d.A * 4);                         // dGgt[H][A] = one-hot(aid)^T dSh, transposed
     w.partial = take((size_t)NCX_COLSUM_CHUNKS * H * 4 * 2 + 256);
     GemmUse u[U_COUNT];
     list_uses(d, u);
@@ -739,9 +740,13 @@ int ncx_backward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, 
         rc = run_gemm(U_DW1S, a, FORM_TN, u[U_DW1S].plan, slab, w.slab_bytes, nullptr, s); if (rc) return rc;
     }
     if (aemb) {
-        {   // dE[a][j] = sum_n dGt[n][a] W1ak[n][j]
-            GemmArgs a{}; a.mode = MODE_GROUP; a.nseg = 1; a.M = d.A;
-            a.a[0] = x_plain(dgt, d.A, H, d.A); a.b[0] = x_plain(p->w1 + o.a_other, din, H, d.da); a.klen[0] = H;
+        {   // dE[a][j] = sum_n dGt[n][a] W1ak[n][j] + sum_n dGgt[n][a] W1agt[n][j],  dGgt = one-hot(aid)^T dSh
+            NCX_HIP_TRY(hipMemsetAsync(dagt, 0, (size_t)H * d.A * 4, s));
+            hipLaunchKernelGGL(k_scatter_dsh_by_answer, dim3(d.B), dim3(256), 0, s, (const float*)dsh, in->answer_aids, d.B, H, d.A, dagt);
+            NCX_HIP_TRY(hipGetLastError());
+            GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 2; a.M = d.A;
+            a.a[0] = x_plain(dgt, d.A, H, d.A);  a.b[0] = x_plain(p->w1 + o.a_other, din, H, d.da); a.klen[0] = H;
+            a.a[1] = x_plain(dagt, d.A, H, d.A); a.b[1] = x_plain(p->w1 + o.a_gt, din, H, d.da);    a.klen[1] = H;
             a.out[0] = g->answer_embedding; a.ldo[0] = d.da; a.n_cols[0] = d.da;
             rc = run_gemm(U_DE, a, FORM_TN, u[U_DE].plan, slab, w.slab_bytes, nullptr, s); if (rc) return rc;
         }
@@ -750,14 +755,6 @@ int ncx_backward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, 
             a.a[0] = x_plain(dgt, d.A, H, d.A); a.b[0] = x_plain(p->answer_embedding, d.da, d.A, d.da); a.klen[0] = d.A;
             a.out[0] = g->w1 + o.a_other; a.ldo[0] = din; a.n_cols[0] = d.da;
             rc = run_gemm(U_DW1AK, a, FORM_NN, u[U_DW1AK].plan, slab, w.slab_bytes, nullptr, s); if (rc) return rc;
-        }
-        {   // dA_gt[b][j] = sum_n dSh[b][n] W1agt[n][j];  dE[aid[b]] += dA_gt[b]
-            GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = d.B;
-            a.a[0] = x_plain(dsh, H, d.B, H); a.b[0] = x_plain(p->w1 + o.a_gt, din, H, d.da); a.klen[0] = H;
-            a.out[0] = dagt; a.ldo[0] = d.da; a.n_cols[0] = d.da;
-            rc = run_gemm(U_DAGT, a, FORM_NN, u[U_DAGT].plan, slab, w.slab_bytes, nullptr, s); if (rc) return rc;
-            hipLaunchKernelGGL(k_scatter_rows_dedup, dim3(d.B), dim3(256), 0, s, (const float*)dagt, in->answer_aids, d.B, d.da, g->answer_embedding);
-            NCX_HIP_TRY(hipGetLastError());
         }
     } else {
         NCX_HIP_TRY(hipMemsetAsync(g->answer_embedding, 0, (size_t)d.A * d.da * 4, s));

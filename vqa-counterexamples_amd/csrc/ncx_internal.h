@@ -51,7 +51,7 @@ struct WsLayout {
     size_t dpre[2];                     // [M][H] ping-pong of pre-activation gradients
     size_t dsh;                         // [B][H]
     size_t dgt;                         // [H][A]
-    size_t dagt;                        // [B][da]
+    size_t dagt;                        // dGgt [H][A]
     size_t partial;                     // column-sum partials [NCX_COLSUM_CHUNKS][H] x 2 + scalars
     size_t slab;                        // split-K slabs (max over all uses)
     size_t slab_bytes;
