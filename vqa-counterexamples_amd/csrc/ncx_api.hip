@@ -328,6 +328,11 @@ static int choose_split(long long tiles, long long ksteps, long long slots) {
     long long sp = cdiv(6 * slots, tiles);
     const long long smax = ksteps / 24 > 1 ? ksteps / 24 : 1;
     if (sp > smax) sp = smax;
+    if (tiles * sp < slots) {                      // cannot even fill one round: trade pipeline depth for parallelism
+        const long long smax2 = ksteps / 8 > 1 ? ksteps / 8 : 1;
+        sp = cdiv(slots, tiles);
+        if (sp > smax2) sp = smax2;
+    }
     return (int)(sp < 1 ? 1 : sp);
 }
 

@@ -251,7 +251,7 @@ struct OpLoader {
     // ---- interior fast path: no bounds handling, kind compile-time, straight-line -------------------
     // KIND: COLK operands have their row pointers resolved in setup(), so X_GATHER == X_PLAIN there.
     template <int KIND>
-    __device__ __forceinline__ void issue_fast(const XDesc& d, int k, int tid) {
+    __device__ __forceinline__ void issue_fast(const XDesc& d, int k, int tid, int idx_ahead = GEMM_BK) {
 #ifdef NCX_ABLATE_LOADS          // timing experiment only: keep the registers of the first tile
         return;
 #endif
@@ -276,18 +276,19 @@ struct OpLoader {
 #pragma unroll
                 for (int i = 0; i < NV; ++i) v1[i] = *(const f32x4u*)(p1[0] + c + 32 * i);
             }
-            // gather indices of the k-step after this one
-            if (KIND == X_GATHER || KIND == X_GATHER_MUL) nidx0 = d.idx[min(r + GEMM_BK, rows - 1)];
-            if (KIND == X_GATHER_MUL) nidx1 = d.idx2[min(r + GEMM_BK, rows - 1)];
+            // gather indices of this loader's next k-step
+            if (KIND == X_GATHER || KIND == X_GATHER_MUL) nidx0 = d.idx[min(r + idx_ahead, rows - 1)];
+            if (KIND == X_GATHER_MUL) nidx1 = d.idx2[min(r + idx_ahead, rows - 1)];
         }
     }
     template <int KIND>
-    __device__ __forceinline__ void store_fast(float* lds, int tid) const {
+    __device__ __forceinline__ void store_fast(float* lds, int tid, int i0 = 0, int i1 = NV) const {
 #ifdef NCX_ABLATE_STORES         // timing experiment only
         return;
 #endif
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
+            if (i < i0 || i >= i1) continue;
             const int ri = COLK ? i : 0;
             f32x4 v = v0[i];
             if (KIND == X_GATHER_MUL) {
@@ -556,6 +557,87 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
         }
         la.resync_after_fast(); lb.resync_after_fast();
     };
+    // Depth-2 variant for the big tiles (one workgroup per CU, registers to spare): the loads of tile t+2 are
+    // issued while tile t is multiplied and tile t+1 (loaded a whole k-step ago, so never waited for) is
+    // transformed and written to LDS spread over sub-steps 1 and 2.  Measured by ablation on the depth-1 loop:
+    // load waits and the clustered store phase cost ~10 % each.
+    auto fast_run2 = [&](auto akind_c, auto bkind_c, int nfast, int& buf) {
+        constexpr int AK = decltype(akind_c)::value, BKD = decltype(bkind_c)::value;
+        const XDesc& da = adesc(seg);
+        const XDesc& db = args.b[seg];
+        typename Cfg::ALoad la2 = la;
+        typename Cfg::BLoad lb2 = lb;
+        la.template issue_fast<AK>(da, kpos + BK, tid, 2 * BK);        // tile t+1 (indices prefetched by the caller)
+        lb.template issue_fast<BKD>(db, kpos + BK, tid, 2 * BK);
+        la2.prefetch_rows(da, kpos + 2 * BK, tid);
+        lb2.prefetch_rows(db, kpos + 2 * BK, tid);
+        auto body = [&](auto issue_c, typename Cfg::ALoad& sa, typename Cfg::BLoad& sb, typename Cfg::ALoad& ia, typename Cfg::BLoad& ib) {
+            constexpr bool ISSUE = decltype(issue_c)::value;
+            kpos += BK;                                                  // kpos = tile being stored (t+1)
+            const float* pa = lds_a + buf * Cfg::A_ELEMS;
+            const float* pb = lds_b + buf * Cfg::B_ELEMS;
+            float* wa = lds_a + (buf ^ 1) * Cfg::A_ELEMS;
+            float* wb = lds_b + (buf ^ 1) * Cfg::B_ELEMS;
+            f32x2 af0[WM], bf0[WN], af1[WM], bf1[WN];
+            constexpr int NVA = Cfg::ALoad::NV, NVB = Cfg::BLoad::NV;
+            read_frags(pa, pb, 0, af0, bf0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ISSUE) {
+                ia.template issue_fast<AK>(da, kpos + BK, tid, 2 * BK);
+                ib.template issue_fast<BKD>(db, kpos + BK, tid, 2 * BK);
+            }
+            read_frags(pa, pb, 1, af1, bf1);
+            mfma_frags(af0, bf0);
+#pragma unroll
+            for (int q = 0; q < NMFMA; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(pa, pb, 2, af0, bf0);
+            sa.template store_fast<AK>(wa, tid, 0, (NVA + 1) / 2);
+            sb.template store_fast<BKD>(wb, tid, 0, (NVB + 1) / 2);
+            mfma_frags(af1, bf1);
+#pragma unroll
+            for (int q = 0; q < NMFMA; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            read_frags(pa, pb, 3, af1, bf1);
+            sa.template store_fast<AK>(wa, tid, (NVA + 1) / 2, NVA);
+            sb.template store_fast<BKD>(wb, tid, (NVB + 1) / 2, NVB);
+            mfma_frags(af0, bf0);
+#pragma unroll
+            for (int q = 0; q < NMFMA; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_frags(af1, bf1);
+            __syncthreads();
+            buf ^= 1;
+        };
+        typedef std::true_type T; typedef std::false_type F;
+        int it = 0;
+        for (; it + 3 <= nfast; it += 2) { body(T{}, la, lb, la2, lb2); body(T{}, la2, lb2, la, lb); }
+        if (nfast - it == 2) { body(T{}, la, lb, la2, lb2); body(F{}, la2, lb2, la, lb); }
+        else                 { body(F{}, la, lb, la2, lb2); }
+        la.resync_after_fast(); lb.resync_after_fast();
+        la.prefetch_rows(da, kpos + BK, tid);                            // re-arm the generic path's index prefetch
+        lb.prefetch_rows(db, kpos + BK, tid);
+    };
+    constexpr bool DEPTH2 = BM * BN >= 96 * 128;
+    auto fast_dispatch = [&](auto akind_c, auto bkind_c, int nfast, int& buf) {
+        if constexpr (DEPTH2) fast_run2(akind_c, bkind_c, nfast, buf);
+        else fast_run(akind_c, bkind_c, nfast, buf);
+    };
     const bool tile_interior = m0 + BM <= M && n0 + BN <= N;
 
     // ---- main loop ------------------------------------------------------------------------------
@@ -590,14 +672,14 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
                 typedef std::integral_constant<int, X_GATHER_MUL> KM;
                 typedef std::integral_constant<int, X_SOFTMAX> KS;
                 if (bk == X_PLAIN) {
-                    if (ak == X_PLAIN) fast_run(KP{}, KP{}, nfast, buf);
-                    else if (A_COLK && B_COLK && ak == X_GATHER_MUL) fast_run(KM{}, KP{}, nfast, buf);
-                    else if (A_COLK && B_COLK && ak == X_SOFTMAX) fast_run(KS{}, KP{}, nfast, buf);
+                    if (ak == X_PLAIN) fast_dispatch(KP{}, KP{}, nfast, buf);
+                    else if (A_COLK && B_COLK && ak == X_GATHER_MUL) fast_dispatch(KM{}, KP{}, nfast, buf);
+                    else if (A_COLK && B_COLK && ak == X_SOFTMAX) fast_dispatch(KS{}, KP{}, nfast, buf);
                     else done = false;
                 } else if (!A_COLK && !B_COLK && ak == X_PLAIN) {
-                    if (bk == X_GATHER) fast_run(KP{}, KG{}, nfast, buf);
-                    else if (bk == X_GATHER_MUL) fast_run(KP{}, KM{}, nfast, buf);
-                    else if (bk == X_SOFTMAX) fast_run(KP{}, KS{}, nfast, buf);
+                    if (bk == X_GATHER) fast_dispatch(KP{}, KG{}, nfast, buf);
+                    else if (bk == X_GATHER_MUL) fast_dispatch(KP{}, KM{}, nfast, buf);
+                    else if (bk == X_SOFTMAX) fast_dispatch(KP{}, KS{}, nfast, buf);
                     else done = false;
                 } else {
                     done = false;
