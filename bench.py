@@ -156,8 +156,11 @@ def main():
         # segment is consumed in its re-associated form softmax(a) . (E . W^T): A columns instead of da)
         p_cols = 2 * c["dv"] + 1 + c["dz"] + c["A"]
         flops_main = 2.0 * M * c["H"] * p_cols
-        names = {"MAIN": "seg_gemm NT 96x128 (linear_1 candidate segments, fwd)",
-                 "DW1C": "seg_gemm TN 128x128 stream-K (linear_1 candidate-column weight grad + dGt, incl. fix-up)"}
+        d0 = eng._dims(pool[0][0], True, 1.0 / gb)
+        plans = {k: _lib.plan_query(d0, k) for k in ("MAIN", "DW1C")}
+        names = {"MAIN": "seg_gemm NT %s (linear_1 candidate segments, fwd)" % plans["MAIN"]["tile"],
+                 "DW1C": "seg_gemm TN %s, %d aligned-split workgroups (linear_1 candidate-column weight grad + dGt, incl. fix-up)"
+                         % (plans["DW1C"]["tile"], plans["DW1C"]["streamk_wgs"])}
         per = {k: sum(v) / len(v) for k, v in prof.items() if v}
         dom = max(per, key=per.get) if per else None
         roof = None
@@ -167,7 +170,7 @@ def main():
                         unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
                         launch_ms=round(per[dom], 4), algorithmic_gflop_per_launch=round(flops_main / 1e9, 3),
                         other={k: dict(launch_ms=round(v, 4), tflops=round(flops_main / (v * 1e-3) / 1e12, 2),
-                                       plan=_lib.plan_query(eng._dims(pool[0][0], True, 1.0 / gb), k)) for k, v in per.items()})
+                                       plan=plans[k]) for k, v in per.items()})
         out = dict(metric="VQA-CX triplets/sec (24 candidates each), NeuralCX training step",
                    value=round(gb * args.steps / dt, 1), unit="triplets/s", n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True,
