@@ -159,8 +159,8 @@ def main():
         d0 = eng._dims(pool[0][0], True, 1.0 / gb)
         plans = {k: _lib.plan_query(d0, k) for k in ("MAIN", "DW1C")}
         names = {"MAIN": "seg_gemm NT %s (linear_1 candidate segments, fwd)" % plans["MAIN"]["tile"],
-                 "DW1C": "seg_gemm TN %s, %d aligned-split workgroups (linear_1 candidate-column weight grad + dGt, incl. fix-up)"
-                         % (plans["DW1C"]["tile"], plans["DW1C"]["streamk_wgs"])}
+                 "DW1C": "seg_gemm TN %s grouped, %d-way aligned split-K (all linear_1 weight-grad columns + dGt, incl. fix-up)"
+                         % (plans["DW1C"]["tile"], plans["DW1C"]["ksplit"])}
         per = {k: sum(v) / len(v) for k, v in prof.items() if v}
         dom = max(per, key=per.get) if per else None
         roof = None

@@ -141,9 +141,9 @@ int ncx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 /* ---- diagnostics (bench.py / tests only; the only process-global state, off by default) --------------
  * GEMM ids: 0 Gt = W1[:,a_other].E^T, 1 Sh (shared segments), 2 MAIN (candidate segments, the dominant
  * forward kernel), 3 hidden layer l>=2 forward, 4 dW1 candidate columns (+dGt; the dominant backward
- * kernel), 5 dW1 shared columns, 6 dE, 7 dW1[:,a_other], 8 dA_gt, 9 dW_l (l>=2), 10 dX_l (l>=2).
+ * kernel; the shared columns ride in the same launch), 5 (unused: merged into 4), 6 dE, 7 dW1[:,a_other], 8 dA_gt, 9 dW_l (l>=2), 10 dX_l (l>=2).
  * ncx_profile_begin arms HIP-event timing (on the launch stream) of every launch of the gemm ids in the mask,
- * including a stream-K fix-up; ncx_profile_end synchronises those events, writes up to `cap` (duration ms, id)
+ * including a split-K fix-up; ncx_profile_end synchronises those events, writes up to `cap` (duration ms, id)
  * pairs and returns how many, then disarms.  Not thread safe; do not arm during graph capture. */
 #define NCX_GEMM_GT 0
 #define NCX_GEMM_SH 1
@@ -159,7 +159,7 @@ int ncx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int ncx_profile_begin(uint32_t gemm_mask /* bit i = gemm id i */, int32_t max_launches);
 int ncx_profile_end(float* ms, int32_t* ids, int32_t cap);
 /* out6 = {form (0 NT,1 TN,2 NN), M, N, 32-deep k-steps, tile cfg (0 64x64, 1 128x128, 2 96x128),
- *         stream-K workgroups (0 = one workgroup per output tile)} */
+ *         aligned k-chunks per output tile (1 = no split)} */
 int ncx_plan_query(const ncx_dims* d, int32_t gemm_id, int32_t* out6);
 
 /* Library build id ("neuralcx-hip gfx950 <date>"). */

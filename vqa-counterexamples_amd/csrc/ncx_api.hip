@@ -338,31 +338,27 @@ static int choose_split(long long tiles, long long ksteps, long long slots) {
 
 // tiles_small: output tiles with 64x64 blocks; ksteps: 32-deep reduction steps per tile.
 static GemmPlan plan_from_tiles(int form, long long tiles_big, long long tiles_small, long long ksteps, bool big_ok) {
-    GemmPlan p; p.ksplit = 1; p.sk_wgs = 0;
+    GemmPlan p; p.split = 1;
     if (big_ok && tiles_big >= 192 && ksteps >= 64) { p.cfg = CFG_128x128; return p; }
-    // Measured on MI355X (DW1C, 104 big / 412 small tiles x 384 k-steps): the 128x128 TN/NT instantiations spill
-    // (233 VGPRs) and reach 0.75-0.81 ms at any split, the spill-free 64x64 tile 0.54 ms: split problems use it.
-    const char* force_big = getenv("NCX_SPLIT_BIG");
-    p.cfg = (force_big && atoi(force_big) && big_ok) ? CFG_128x128 : CFG_64x64;
-    const long long tiles = p.cfg == CFG_128x128 ? tiles_big : tiles_small;
+    // Measured on MI355X (DW1C, 412 small tiles x 384 k-steps): every TN tile shape (64x64, 128x64, 128x128) ends
+    // at 0.45-0.51 ms; the 64x64 tile fits 3 workgroups per CU and is used for all split problems.
+    p.cfg = CFG_64x64;
     const int occ = form == FORM_NT ? occupancy_nt(p.cfg) : form == FORM_TN ? occupancy_tn(p.cfg) : occupancy_nn(p.cfg);
-    const long long slots = (long long)occ * num_cus();
-    const int sp = choose_split(tiles, ksteps, slots);
-    if (sp > 1) p.sk_wgs = (int)(tiles * sp);
+    p.split = choose_split(tiles_small, ksteps, (long long)occ * num_cus());
     return p;
 }
 
 GemmPlan plan_gemm(int form, long long M, long long N, long long ksteps, bool allow_96) {
     if (form == FORM_NT && allow_96 && M % 96 == 0 && N % 128 == 0 && (M / 96) * (N / 128) >= 192 &&
         (M % 128 != 0 || cdiv(M, 128) * cdiv(N, 128) < 256)) {
-        GemmPlan p; p.cfg = CFG_96x128; p.ksplit = 1; p.sk_wgs = 0; return p;
+        GemmPlan p; p.cfg = CFG_96x128; p.split = 1; return p;
     }
     const bool big_ok = M >= 96 && N >= 96;
     return plan_from_tiles(form, cdiv(M, 128) * cdiv(N, 128), cdiv(M, 64) * cdiv(N, 64), ksteps, big_ok);
 }
 
 // The GEMMs of one step, so that ws_layout and forward/backward agree on split-K slab sizes.
-struct GemmUse { int form; long long M, N, ksteps; bool allow96; GemmPlan plan; long long slab_elems; };
+struct GemmUse { int form; long long M, N, ksteps; bool allow96; GemmPlan plan; long long slab_elems; long long tiles; };
 enum { U_GT = 0, U_SH, U_MAIN, U_FWD_L, U_DW1C, U_DW1S, U_DE, U_DW1AK, U_DAGT, U_DWL, U_DXL, U_COUNT };
 
 static inline long long ks(long long k) { return cdiv(k, GEMM_BK); }
@@ -386,41 +382,39 @@ static void list_uses(const ncx_dims& d, GemmUse* u) {
     u[U_DWL]   = {FORM_TN, H, H, ks(M), false};
     u[U_DXL]   = {FORM_NN, M, H, ks(H), false};
     for (int i = 0; i < U_COUNT; ++i) {
+        long long tb = cdiv(u[i].M, 128) * cdiv(u[i].N, 128), ts = cdiv(u[i].M, 64) * cdiv(u[i].N, 64);
         if (i == U_DW1C || i == U_DW1S) {                       // grouped: tiles are counted per column segment
-            long long tb = 0, ts = 0;
+            tb = ts = 0;
             const long long segs_c[5] = {d.dv, (d.flags & NCX_F_V_MULT) ? d.dv : 0, d.K + 1, d.dz, aemb ? d.A : d.da};
             const long long segs_s[5] = {d.dv, d.dq, d.dz, d.da, 0};
             const long long* sg = i == U_DW1C ? segs_c : segs_s;
             for (int q = 0; q < 5; ++q) { tb += cdiv(H, 128) * cdiv(sg[q], 128); ts += cdiv(H, 64) * cdiv(sg[q], 64); }
-            u[i].plan = plan_from_tiles(FORM_TN, tb, ts, u[i].ksteps, H >= 96);
+            u[i].plan = plan_from_tiles(FORM_TN, tb, ts, u[i].ksteps, false);
         } else {
             u[i].plan = plan_gemm(u[i].form, u[i].M, u[i].N, u[i].ksteps, u[i].allow96);
         }
-        if (i == U_MAIN || i == U_FWD_L || i == U_DXL) { u[i].plan.ksplit = 1; u[i].plan.sk_wgs = 0; }   // epilogue GEMMs never split
-        {   // experiment hook: NCX_SPLIT_<id>=S forces S aligned k-chunks (0 = no split), NCX_CFG_<id>=0|1 the tile
+        if (i == U_MAIN || i == U_FWD_L || i == U_DXL) u[i].plan.split = 1;       // epilogue GEMMs never split
+        {   // experiment hooks: NCX_SPLIT_<id>=S forces S aligned k-chunks, NCX_CFG_<id> the tile config
             char name[32];
-            snprintf(name, sizeof name, "NCX_SPLIT_%d", i);
-            const char* e = getenv(name);
             snprintf(name, sizeof name, "NCX_CFG_%d", i);
             const char* c = getenv(name);
-            if (c) u[i].plan.cfg = atoi(c);       // 0 64x64, 1 128x128, 2 96x128 (NT only), 3 96x64 (NT only)
-            if (e && i != U_MAIN && i != U_FWD_L && i != U_DXL) {
-                int bm0, bn0; cfg_tile(u[i].plan.cfg, bm0, bn0);
-                long long t = 0;
-                if (i == U_DW1C || i == U_DW1S) {
-                    const long long segs_c[5] = {d.dv, (d.flags & NCX_F_V_MULT) ? d.dv : 0, d.K + 1, d.dz, aemb ? d.A : d.da};
-                    const long long segs_s[5] = {d.dv, d.dq, d.dz, d.da, 0};
-                    const long long* sg = i == U_DW1C ? segs_c : segs_s;
-                    for (int q = 0; q < 5; ++q) t += cdiv(H, bm0) * cdiv(sg[q], bn0);
-                } else {
-                    t = cdiv(u[i].M, bm0) * cdiv(u[i].N, bn0);
-                }
-                const int sp = atoi(e);
-                u[i].plan.sk_wgs = sp > 1 ? (int)(t * sp) : 0;
-            }
+            if (c) u[i].plan.cfg = atoi(c);
+            snprintf(name, sizeof name, "NCX_SPLIT_%d", i);
+            const char* e = getenv(name);
+            if (e && i != U_MAIN && i != U_FWD_L && i != U_DXL) u[i].plan.split = atoi(e) > 1 ? atoi(e) : 1;
         }
         int bm, bn; cfg_tile(u[i].plan.cfg, bm, bn);
-        u[i].slab_elems = u[i].plan.sk_wgs > 0 ? (long long)u[i].plan.sk_wgs * 2 * bm * bn : 0;
+        long long tiles = cdiv(u[i].M, bm) * cdiv(u[i].N, bn);
+        if (i == U_DW1C || i == U_DW1S) tiles = u[i].plan.cfg == CFG_128x128 ? tb : ts;
+        u[i].tiles = tiles;
+        u[i].slab_elems = u[i].plan.split > 1 ? tiles * u[i].plan.split * bm * bn : 0;
+    }
+    // DW1S rides in DW1C's launch (same tile config): its workgroups' slab slots follow DW1C's
+    u[U_DW1S].plan.cfg = u[U_DW1C].plan.cfg;
+    {
+        int bm, bn; cfg_tile(u[U_DW1C].plan.cfg, bm, bn);
+        u[U_DW1C].slab_elems = (u[U_DW1C].tiles * u[U_DW1C].plan.split + u[U_DW1S].tiles * u[U_DW1S].plan.split) * bm * bn;
+        u[U_DW1S].slab_elems = 0;
     }
 }
 
@@ -484,23 +478,19 @@ static int run_gemm(int use_id, GemmArgs& a, int form, const GemmPlan& pl, float
 
 static int run_gemm_impl(GemmArgs& a, int form, const GemmPlan& pl, float* slab, size_t slab_bytes,
                          const float* reduce_bias, hipStream_t s) {
-    a.ksplit = 1;
-    a.sk_wgs = 0;
-    if (pl.sk_wgs > 0) {
-        int bm, bn; cfg_tile(pl.cfg, bm, bn);
-        if ((size_t)pl.sk_wgs * 2 * bm * bn * 4 > slab_bytes) return NCX_E_WORKSPACE;
-        long long steps = 0;
-        if (a.mode == MODE_GROUP) {
-            steps = cdiv(a.klen[0], GEMM_BK);
-            for (int i = 1; i < a.nseg; ++i) if (cdiv(a.klen[i], GEMM_BK) != steps) return NCX_E_DIMS;
-        } else {
-            for (int i = 0; i < a.nseg; ++i) steps += cdiv(a.klen[i], GEMM_BK);
-        }
-        a.sk_wgs = pl.sk_wgs; a.sk_steps = (int)steps; a.sk_slab = slab;
-        a.epi.bias = reduce_bias;                                 // applied by the fix-up kernel
-    } else if (reduce_bias) {
-        a.epi.bias = reduce_bias;
+    const int np = a.mode == MODE_GROUP ? a.nseg : 1;
+    bool any = false;
+    for (int i = 0; i < np; ++i) {
+        if (a.split[i] == 0) a.split[i] = pl.split;              // callers may preset per-problem splits
+        any |= a.split[i] > 1;
     }
+    if (any) {
+        int bm, bn; cfg_tile(pl.cfg, bm, bn);
+        const long long wgs = gemm_layout(a, bm, bn, nullptr);
+        if ((size_t)wgs * bm * bn * 4 > slab_bytes) return NCX_E_WORKSPACE;
+        a.slab = slab;
+    }
+    if (reduce_bias) a.epi.bias = reduce_bias;                   // applied by the epilogue or by the fix-up kernel
     if (form == FORM_NT) return run_gemm_nt(a, pl.cfg, s);
     if (form == FORM_TN) return run_gemm_tn(a, pl.cfg, s);
     return run_gemm_nn(a, pl.cfg, s);
@@ -713,36 +703,33 @@ int ncx_backward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, 
     hipLaunchKernelGGL(k_rowgroup_sum, dim3((unsigned)cdiv((long long)d.B * H, 256)), dim3(256), 0, s, (const float*)dpre, d.B, d.K, H, dsh);
     NCX_HIP_TRY(hipGetLastError());
     rc = colsum(dsh, nullptr, d.B, H, g->b1); if (rc) return rc;
-    {   // candidate columns of dW1 (+ dGt): dpre^T . X_seg
+    {   // dW1 = [dpre^T . candidate segments (+ dGt) | dSh^T . shared segments]: ONE grouped launch, per-problem
+        // reduction extent (M rows of dpre vs B rows of dSh) and k-split
         GemmArgs a{}; a.mode = MODE_GROUP; a.M = H;
-        a.a[0] = x_plain(dpre, H, M, H);
         int n = 0;
-        auto add = [&](const XDesc& x, float* out, long long ldo) { a.b[n] = x; a.klen[n] = M; a.out[n] = out; a.ldo[n] = ldo; a.n_cols[n] = x.cols; ++n; };
-        add(x_gather(in->feats, d.dv, idx_k, M, d.dv), g->w1 + o.v_other, din);
-        if (d.flags & NCX_F_V_MULT) add(x_gather_mul(in->feats, d.dv, idx_k, idx_o, M, d.dv), g->w1 + o.v_mult, din);
-        add(x_plain(misc, d.K + 1, M, d.K + 1), g->w1 + o.v_dist, din);
-        add(x_plain(in->z_knns, d.dz, M, d.dz), g->w1 + o.z_other, din);
-        if (aemb) add(x_softmax(in->a_knns, d.A, mx, inv, M, d.A), dgt, d.A);
-        else      add(x_plain(in->a_knns, d.da, M, d.da), g->w1 + o.a_other, din);
+        auto add_c = [&](const XDesc& x, float* out, long long ldo) {
+            a.a[n] = x_plain(dpre, H, M, H); a.b[n] = x; a.klen[n] = M; a.out[n] = out; a.ldo[n] = ldo; a.n_cols[n] = x.cols;
+            a.split[n] = u[U_DW1C].plan.split; ++n; };
+        auto add_s = [&](const XDesc& x, float* out) {
+            a.a[n] = x_plain(dsh, H, d.B, H); a.b[n] = x; a.klen[n] = d.B; a.out[n] = out; a.ldo[n] = din; a.n_cols[n] = x.cols;
+            a.split[n] = u[U_DW1S].plan.split; ++n; };
+        add_c(x_gather(in->feats, d.dv, idx_k, M, d.dv), g->w1 + o.v_other, din);
+        if (d.flags & NCX_F_V_MULT) add_c(x_gather_mul(in->feats, d.dv, idx_k, idx_o, M, d.dv), g->w1 + o.v_mult, din);
+        add_c(x_plain(misc, d.K + 1, M, d.K + 1), g->w1 + o.v_dist, din);
+        add_c(x_plain(in->z_knns, d.dz, M, d.dz), g->w1 + o.z_other, din);
+        if (aemb) add_c(x_softmax(in->a_knns, d.A, mx, inv, M, d.A), dgt, d.A);
+        else      add_c(x_plain(in->a_knns, d.da, M, d.da), g->w1 + o.a_other, din);
+        add_s(x_gather(in->feats, d.dv, idx_ob, d.B, d.dv), g->w1 + o.v_orig);
+        add_s(x_plain(in->q_emb, d.dq, d.B, d.dq), g->w1 + o.q_emb);
+        add_s(x_plain(in->z_orig, d.dz, d.B, d.dz), g->w1 + o.z_orig);
+        add_s(aemb ? x_gather(p->answer_embedding, d.da, in->answer_aids, d.B, d.da) : x_plain(in->a_emb_gt, d.da, d.B, d.da),
+              g->w1 + o.a_gt);
         a.nseg = n;
         rc = run_gemm(U_DW1C, a, FORM_TN, u[U_DW1C].plan, slab, w.slab_bytes, nullptr, s); if (rc) return rc;
         if (!(d.flags & NCX_F_V_MULT)) {
             hipLaunchKernelGGL(k_zero_cols, dim3((unsigned)cdiv((long long)H * d.dv, 256)), dim3(256), 0, s, g->w1 + o.v_mult, H, din, d.dv);
             NCX_HIP_TRY(hipGetLastError());
         }
-    }
-    {   // shared columns of dW1: dSh^T . X_shared
-        GemmArgs a{}; a.mode = MODE_GROUP; a.M = H;
-        a.a[0] = x_plain(dsh, H, d.B, H);
-        int n = 0;
-        auto add = [&](const XDesc& x, float* out) { a.b[n] = x; a.klen[n] = d.B; a.out[n] = out; a.ldo[n] = din; a.n_cols[n] = x.cols; ++n; };
-        add(x_gather(in->feats, d.dv, idx_ob, d.B, d.dv), g->w1 + o.v_orig);
-        add(x_plain(in->q_emb, d.dq, d.B, d.dq), g->w1 + o.q_emb);
-        add(x_plain(in->z_orig, d.dz, d.B, d.dz), g->w1 + o.z_orig);
-        add(aemb ? x_gather(p->answer_embedding, d.da, in->answer_aids, d.B, d.da) : x_plain(in->a_emb_gt, d.da, d.B, d.da),
-            g->w1 + o.a_gt);
-        a.nseg = n;
-        rc = run_gemm(U_DW1S, a, FORM_TN, u[U_DW1S].plan, slab, w.slab_bytes, nullptr, s); if (rc) return rc;
     }
     if (aemb) {
         {   // dE[a][j] = sum_n dGt[n][a] W1ak[n][j] + sum_n dGgt[n][a] W1agt[n][j],  dGgt = one-hot(aid)^T dSh
@@ -816,7 +803,7 @@ int ncx_plan_query(const ncx_dims* d, int32_t gemm_id, int32_t* out6) {
     GemmUse u[U_COUNT];
     list_uses(*d, u);
     out6[0] = u[gemm_id].form; out6[1] = (int32_t)u[gemm_id].M; out6[2] = (int32_t)u[gemm_id].N;
-    out6[3] = (int32_t)u[gemm_id].ksteps; out6[4] = u[gemm_id].plan.cfg; out6[5] = u[gemm_id].plan.sk_wgs;
+    out6[3] = (int32_t)u[gemm_id].ksteps; out6[4] = u[gemm_id].plan.cfg; out6[5] = u[gemm_id].plan.split;
     return NCX_OK;
 }
 

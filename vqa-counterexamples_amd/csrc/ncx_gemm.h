@@ -60,7 +60,7 @@ static inline XDesc x_softmax(const float* logits, long long ld, const float* mx
     XDesc d{}; d.base = logits; d.ld = ld; d.mx = mx; d.inv = inv; d.kind = X_SOFTMAX; d.rows = rows; d.cols = cols; return d;
 }
 
-constexpr int NCX_MAX_SEG = 6;
+constexpr int NCX_MAX_SEG = 10;
 constexpr int GEMM_BK = 32;
 
 enum GemmMode : int { MODE_CHAIN = 0, MODE_GROUP = 1 };
@@ -78,18 +78,17 @@ struct EpiArgs {
 };
 
 struct GemmArgs {
-    XDesc a[NCX_MAX_SEG];
+    XDesc a[NCX_MAX_SEG];        // CHAIN: a[s] of pair s;  GROUP: a[i] of problem i
     XDesc b[NCX_MAX_SEG];
     int   klen[NCX_MAX_SEG];     // reduction extent of pair/problem i
     float* out[NCX_MAX_SEG];     // CHAIN: out[0];  GROUP: one per problem
     long long ldo[NCX_MAX_SEG];
     int   n_cols[NCX_MAX_SEG];   // N of problem i (CHAIN: n_cols[0])
-    int   tile0[NCX_MAX_SEG + 1];// GROUP: first linear tile id of problem i
-    int   mode, nseg, M, ksplit;
-    long long split_stride;      // elements between split-K slabs of out (ksplit > 1)
-    int   sk_wgs;                // > 0: stream-K: sk_wgs workgroups share tiles x sk_steps k-step units evenly
-    int   sk_steps;              // k-steps per tile (equal for every tile)
-    float* sk_slab;              // [sk_wgs][2][BM*BN] partial tiles
+    int   split[NCX_MAX_SEG];    // aligned k-chunks per output tile of problem i (CHAIN: split[0]); <= 1: none
+    int   tile0[NCX_MAX_SEG + 1];// first linear tile id of problem i           (filled by the launcher)
+    int   wg0[NCX_MAX_SEG + 1];  // first workgroup id of problem i = sum tiles*split (filled by the launcher)
+    int   mode, nseg, M, pad_;
+    float* slab;                 // [workgroups][BM*BN] partial tiles of the split problems
     EpiArgs epi;
 };
 
@@ -361,47 +360,26 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
     const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
 
     const int M = args.M;
-    // ---- stream-K: this workgroup's contiguous range of (tile, k-step) units ----------------------
-    long long sk_u = 0, sk_end = 0;
-    if (args.sk_wgs > 0) {
-        int total_tiles = 0;
-        if (args.mode == MODE_GROUP) total_tiles = args.tile0[args.nseg];
-        else total_tiles = ((M + BM - 1) / BM) * ((args.n_cols[0] + BN - 1) / BN);
-        const long long U = (long long)total_tiles * args.sk_steps;
-        sk_u = U * blockIdx.x / args.sk_wgs;
-        sk_end = U * (blockIdx.x + 1) / args.sk_wgs;
-    }
-    int sk_piece = 0;
     f32x4 acc[WM][WN];
-  for (;;) {                                     // one iteration per piece (exactly one without stream-K)
-    int prob = 0, tile = blockIdx.x, step_begin, step_end;
-    if (args.sk_wgs > 0) {
-        if (sk_u >= sk_end) break;
-        tile = (int)(sk_u / args.sk_steps);
-        step_begin = (int)(sk_u - (long long)tile * args.sk_steps);
-        const long long left = sk_end - sk_u;
-        step_end = (int)(step_begin + left < args.sk_steps ? step_begin + left : args.sk_steps);
-        sk_u += step_end - step_begin;
-    }
-    // ---- which problem / tile -------------------------------------------------------------------
+    // ---- which problem / tile / k-chunk -------------------------------------------------------------
+    // Workgroups of problem p are numbered tile-major, chunk-minor: w = wg0[p] + tile*S + z.  All chunks z of
+    // different tiles advance through the same k range together and share their operand rows in L2.
+    int prob = 0, lw = blockIdx.x;
     if (args.mode == MODE_GROUP) {
-        while (prob + 1 < args.nseg && tile >= args.tile0[prob + 1]) ++prob;
-        tile -= args.tile0[prob];
+        while (prob + 1 < args.nseg && lw >= args.wg0[prob + 1]) ++prob;
+        lw -= args.wg0[prob];
     }
+    const int S = args.split[prob] > 1 ? args.split[prob] : 1;
+    const int tile = lw / S, z = lw - tile * S;
     const int N = args.n_cols[prob];
     const int tiles_n = (N + BN - 1) / BN;
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-
-    // ---- K range of this split ------------------------------------------------------------------
     const int first_seg = args.mode == MODE_GROUP ? prob : 0;
     const int last_seg  = args.mode == MODE_GROUP ? prob + 1 : args.nseg;
-    const int z = blockIdx.y;
-    if (args.sk_wgs <= 0) {
-        int total_steps = 0;
-        for (int s = first_seg; s < last_seg; ++s) total_steps += (args.klen[s] + BK - 1) / BK;
-        step_begin = (int)((long long)total_steps * z / args.ksplit);
-        step_end   = (int)((long long)total_steps * (z + 1) / args.ksplit);
-    }
+    int total_steps = 0;
+    for (int s = first_seg; s < last_seg; ++s) total_steps += (args.klen[s] + BK - 1) / BK;
+    const int step_begin = (int)((long long)total_steps * z / S);
+    const int step_end   = (int)((long long)total_steps * (z + 1) / S);
 
     // cursor: (segment, k position)
     int seg = first_seg, kpos = 0;
@@ -416,7 +394,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
 
     typename Cfg::ALoad la;
     typename Cfg::BLoad lb;
-    auto adesc = [&](int s) -> const XDesc& { return args.a[args.mode == MODE_GROUP ? 0 : s]; };
+    auto adesc = [&](int s) -> const XDesc& { return args.a[s]; };
 
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -716,9 +694,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
     }
 
     // ---- epilogue -------------------------------------------------------------------------------
-    if (args.sk_wgs > 0) {
-        // partial tile -> slab slot (whole padded tile, no bounds: padded operands contribute zeros)
-        float* slot = args.sk_slab + ((long long)blockIdx.x * 2 + sk_piece) * (BM * BN);
+    if (S > 1) {
+        // partial tile -> this workgroup's slab slot (whole padded tile: padded operands contribute zeros)
+        float* slot = args.slab + (long long)blockIdx.x * (BM * BN);
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -726,14 +704,10 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
                     slot[trow(i, lk * 4 + q) * BN + tcol(j, li)] = acc[i][j][q];
-        ++sk_piece;
-        __syncthreads();                    // LDS tiles are reused by the next piece
-        continue;
+        return;
     }
     float* out = args.out[args.mode == MODE_GROUP ? prob : 0];
     const long long ldo = args.ldo[args.mode == MODE_GROUP ? prob : 0];
-    if (args.ksplit > 1) out += (long long)z * args.split_stride;
-    const bool plain = args.ksplit > 1;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -742,56 +716,41 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = m0 + trow(i, lk * 4 + q);
-                if (r < M && n < N) {
-                    float v = acc[i][j][q];
-                    if (!plain) v = apply_epilogue(args.epi, v, r, n, N);
-                    out[(long long)r * ldo + n] = v;
-                }
+                if (r < M && n < N) out[(long long)r * ldo + n] = apply_epilogue(args.epi, acc[i][j][q], r, n, N);
             }
         }
     }
-    break;
-  }   // piece loop
 }
 
-// Stream-K fix-up: tile t = sum of the partial tiles of the workgroups whose unit range overlaps it, in
-// workgroup order (deterministic), + optional bias; scattered to the problem's output with bounds.
+// Split fix-up: output tile t of problem p = sum of its S partial tiles (slab slots wg0[p] + t*S + z, z ascending:
+// deterministic) + optional bias, scattered to the problem's output with bounds.  Unsplit problems are skipped.
 struct FixupArgs {
-    float* out[NCX_MAX_SEG]; long long ldo[NCX_MAX_SEG]; int n_cols[NCX_MAX_SEG]; int tile0[NCX_MAX_SEG + 1];
+    float* out[NCX_MAX_SEG]; long long ldo[NCX_MAX_SEG]; int n_cols[NCX_MAX_SEG]; int split[NCX_MAX_SEG];
+    int tile0[NCX_MAX_SEG + 1]; int wg0[NCX_MAX_SEG + 1];
     const float* bias;
     const float* slab;
-    int mode, nseg, M, sk_wgs, sk_steps, total_tiles;
+    int mode, nseg, M, pad_;
 };
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void streamk_fixup_kernel(const FixupArgs a) {
+__global__ __launch_bounds__(256) void split_fixup_kernel(const FixupArgs a) {
     int tile = blockIdx.x, prob = 0;
-    const int t_lin = tile;
     if (a.mode == MODE_GROUP) {
         while (prob + 1 < a.nseg && tile >= a.tile0[prob + 1]) ++prob;
         tile -= a.tile0[prob];
     }
+    const int S = a.split[prob];
+    if (S <= 1) return;
     const int N = a.n_cols[prob];
     const int tiles_n = (N + BN - 1) / BN;
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-    const long long U = (long long)a.total_tiles * a.sk_steps;
-    const long long u0 = (long long)t_lin * a.sk_steps, u1 = u0 + a.sk_steps - 1;
-    auto owner = [&](long long u) {               // workgroup w with start(w) <= u < start(w+1), start(w) = U*w/W
-        int w = (int)((u * a.sk_wgs) / U);
-        while (w + 1 < a.sk_wgs && U * (w + 1) / a.sk_wgs <= u) ++w;
-        while (w > 0 && U * w / a.sk_wgs > u) --w;
-        return w;
-    };
-    const int w_lo = owner(u0), w_hi = owner(u1);
     float* out = a.out[prob];
     const long long ldo = a.ldo[prob];
     constexpr int E = BM * BN / 1024;                 // float4 per thread
     f32x4 s[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int w = w_lo; w <= w_hi; ++w) {             // workgroup order: deterministic
-        const long long st = U * w / a.sk_wgs;
-        const int slot = (int)(st / a.sk_steps) == t_lin ? 0 : 1;
-        const float* src = a.slab + ((long long)w * 2 + slot) * (BM * BN) + threadIdx.x * 4;
+    const float* src = a.slab + ((long long)a.wg0[prob] + (long long)tile * S) * (BM * BN) + threadIdx.x * 4;
+    for (int z = 0; z < S; ++z, src += BM * BN) {
 #pragma unroll
         for (int i = 0; i < E; ++i) s[i] += *(const f32x4*)(src + i * 1024);
     }
@@ -810,21 +769,28 @@ __global__ __launch_bounds__(256) void streamk_fixup_kernel(const FixupArgs a) {
 }
 
 // ---- host-side launcher ---------------------------------------------------------------------------
+// Workgroups needed by `args` with BM x BN tiles (also fills tile0 / wg0).
+static inline long long gemm_layout(GemmArgs& args, int BM, int BN, bool* any_split) {
+    const int tiles_m = (args.M + BM - 1) / BM;
+    const int np = args.mode == MODE_GROUP ? args.nseg : 1;
+    int tiles = 0; long long wgs = 0; bool sp = false;
+    for (int i = 0; i < np; ++i) {
+        const int t = tiles_m * ((args.n_cols[i] + BN - 1) / BN);
+        const int S = args.split[i] > 1 ? args.split[i] : 1;
+        args.tile0[i] = tiles; args.wg0[i] = (int)wgs;
+        tiles += t; wgs += (long long)t * S; sp |= S > 1;
+    }
+    args.tile0[np] = tiles; args.wg0[np] = (int)wgs;
+    if (any_split) *any_split = sp;
+    return wgs;
+}
+
 template <int BM, int BN, bool A_COLK, bool B_COLK>
 static inline hipError_t launch_seg_gemm(GemmArgs& args, hipStream_t stream) {
     typedef GemmCfg<BM, BN, A_COLK, B_COLK> Cfg;
-    int tiles = 0;
-    const int tiles_m = (args.M + BM - 1) / BM;
-    if (args.mode == MODE_GROUP) {
-        for (int s = 0; s < args.nseg; ++s) {
-            args.tile0[s] = tiles;
-            tiles += tiles_m * ((args.n_cols[s] + BN - 1) / BN);
-        }
-        args.tile0[args.nseg] = tiles;
-    } else {
-        tiles = tiles_m * ((args.n_cols[0] + BN - 1) / BN);
-    }
-    if (tiles == 0) return hipSuccess;
+    bool any_split = false;
+    const long long wgs = gemm_layout(args, BM, BN, &any_split);
+    if (wgs == 0) return hipSuccess;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)seg_gemm_kernel<BM, BN, A_COLK, B_COLK>,
@@ -832,22 +798,15 @@ static inline hipError_t launch_seg_gemm(GemmArgs& args, hipStream_t stream) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    if (args.ksplit < 1) args.ksplit = 1;
-    if (args.sk_wgs > 0) {
-        args.ksplit = 1;
-        hipLaunchKernelGGL((seg_gemm_kernel<BM, BN, A_COLK, B_COLK>), dim3(args.sk_wgs), dim3(256), Cfg::LDS_BYTES, stream, args);
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
-        FixupArgs f{};
-        for (int i = 0; i < NCX_MAX_SEG; ++i) { f.out[i] = args.out[i]; f.ldo[i] = args.ldo[i]; f.n_cols[i] = args.n_cols[i]; f.tile0[i] = args.tile0[i]; }
-        f.tile0[NCX_MAX_SEG] = args.tile0[NCX_MAX_SEG];
-        f.bias = args.epi.bias; f.slab = args.sk_slab; f.mode = args.mode; f.nseg = args.nseg; f.M = args.M;
-        f.sk_wgs = args.sk_wgs; f.sk_steps = args.sk_steps; f.total_tiles = tiles;
-        hipLaunchKernelGGL((streamk_fixup_kernel<BM, BN>), dim3(tiles), dim3(256), 0, stream, f);
-        return hipGetLastError();
-    }
-    dim3 grid(tiles, args.ksplit, 1);
-    hipLaunchKernelGGL((seg_gemm_kernel<BM, BN, A_COLK, B_COLK>), grid, dim3(256), Cfg::LDS_BYTES, stream, args);
+    hipLaunchKernelGGL((seg_gemm_kernel<BM, BN, A_COLK, B_COLK>), dim3((unsigned)wgs), dim3(256), Cfg::LDS_BYTES, stream, args);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !any_split) return e;
+    FixupArgs f{};
+    const int np = args.mode == MODE_GROUP ? args.nseg : 1;
+    for (int i = 0; i < np; ++i) { f.out[i] = args.out[i]; f.ldo[i] = args.ldo[i]; f.n_cols[i] = args.n_cols[i]; f.split[i] = args.split[i]; }
+    for (int i = 0; i <= np; ++i) { f.tile0[i] = args.tile0[i]; f.wg0[i] = args.wg0[i]; }
+    f.bias = args.epi.bias; f.slab = args.slab; f.mode = args.mode; f.nseg = args.nseg; f.M = args.M;
+    hipLaunchKernelGGL((split_fixup_kernel<BM, BN>), dim3(args.tile0[np]), dim3(256), 0, stream, f);
     return hipGetLastError();
 }
 
@@ -867,7 +826,7 @@ static inline int seg_gemm_occupancy() {
 
 // Tile geometry of a config, for the planner.
 static inline void cfg_tile(int cfg, int& bm, int& bn) {
-    bm = cfg == 1 ? 128 : (cfg == 2 || cfg == 3) ? 96 : 64; bn = (cfg == 0 || cfg == 3) ? 64 : 128;
+    bm = (cfg == 1 || cfg == 4) ? 128 : (cfg == 2 || cfg == 3) ? 96 : 64; bn = (cfg == 0 || cfg == 3 || cfg == 4) ? 64 : 128;
 }
 
 #endif  // __HIPCC__

@@ -32,13 +32,15 @@ int occupancy_nt(int cfg) {
 int run_gemm_tn(GemmArgs& a, int cfg, hipStream_t s) {
     switch (cfg) {
     case CFG_128x128: return (int)launch_seg_gemm<128, 128, false, false>(a, s);
+    case CFG_128x64:  return (int)launch_seg_gemm<128, 64, false, false>(a, s);
     default:          return (int)launch_seg_gemm<64, 64, false, false>(a, s);
     }
 }
 int occupancy_tn(int cfg) {
-    static int occ[2] = {0, 0};
-    const int i = cfg == CFG_128x128;
-    if (!occ[i]) occ[i] = i ? seg_gemm_occupancy<128, 128, false, false>() : seg_gemm_occupancy<64, 64, false, false>();
+    static int occ[3] = {0, 0, 0};
+    const int i = cfg == CFG_128x128 ? 1 : cfg == CFG_128x64 ? 2 : 0;
+    if (!occ[i]) occ[i] = i == 1 ? seg_gemm_occupancy<128, 128, false, false>()
+                        : i == 2 ? seg_gemm_occupancy<128, 64, false, false>() : seg_gemm_occupancy<64, 64, false, false>();
     return occ[i];
 }
 #else

@@ -5,7 +5,7 @@
 
 namespace ncx {
 
-enum TileCfg : int { CFG_64x64 = 0, CFG_128x128 = 1, CFG_96x128 = 2, CFG_96x64 = 3 };
+enum TileCfg : int { CFG_64x64 = 0, CFG_128x128 = 1, CFG_96x128 = 2, CFG_96x64 = 3, CFG_128x64 = 4 };
 enum GemmForm : int { FORM_NT = 0, FORM_TN = 1, FORM_NN = 2 };
 
 int run_gemm_nt(GemmArgs& a, int cfg, hipStream_t s);
@@ -36,7 +36,7 @@ static inline SegOffsets seg_offsets(const ncx_dims& d) {
 }
 
 // Split-K plan of one GEMM: tile config + number of K splits (slabs reduced by k_slab_reduce).
-struct GemmPlan { int cfg; int ksplit; int sk_wgs; };   // sk_wgs > 0: stream-K over that many workgroups
+struct GemmPlan { int cfg; int split; };   // split: aligned k-chunks per output tile (1 = none)
 GemmPlan plan_gemm(int form, long long M, long long N, long long ksteps, bool allow_96);
 int num_cus();
 
