@@ -101,12 +101,17 @@ def main():
         raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
+    backend = os.environ.get("NCX_DIST_BACKEND", "nccl")               # "gloo": rehearsal of N ranks on one card
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=dev)      # nccl == RCCL on ROCm
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        else:
+            torch.distributed.init_process_group(backend)
 
     from neuralcx import _lib
     from neuralcx.engine import NeuralCXEngine

@@ -131,6 +131,14 @@ int ncx_backward(const ncx_dims* d, const ncx_inputs* in, const ncx_params* p,
                  void* workspace, size_t workspace_bytes, const float* dscores,
                  const ncx_grads* g, void* stream);
 
+/* ncx_backward in two halves, for overlapping the gradient all-reduce of a data-parallel job with compute
+ * (net-new: the reference is single-GPU).  phase 1 produces out.*, linear_2/3.*, linear_1.bias and the complete
+ * answer_embedding gradient; phase 2 produces linear_1.weight.  Calling 1 then 2 on the same stream and workspace
+ * is bit-identical to ncx_backward (phase 0). */
+int ncx_backward_phase(const ncx_dims* d, const ncx_inputs* in, const ncx_params* p,
+                       void* workspace, size_t workspace_bytes, const float* dscores,
+                       const ncx_grads* g, int32_t phase, void* stream);
+
 /* Replaces torch.optim.Adam(...).step() (counterexamples.py:275-276,339) on a flat fp32 buffer:
  * defaults betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad.  `step` is the 1-based step
  * count; grad_scale multiplies g first (1/world_size after a sum all-reduce). */

@@ -225,3 +225,26 @@ def test_one_train_step_matches_golden_adam():
         # Adam normalises by sqrt(v): entries whose gradient is round-off noise (|g| ~ 1e-9) move by +-lr either way
         big = np.abs(g["grad/" + k].reshape(-1)) > 1e-6 * np.abs(g["grad/" + k]).max()
         assert np.abs(P.cpu().numpy() - ref)[big].max() <= 2e-6, k
+
+
+def test_phased_backward_is_bit_identical():
+    """ncx_backward_phase 1 then 2 == ncx_backward (what the data-parallel engine relies on for comm overlap)."""
+    from neuralcx import ops
+    for L in (1, 2):
+        d = orc.Dims(dv=96, dq=64, dz=24, A=40, H=64, L=L)
+        params = orc.init_params(d, seed=9, gain=3.0)
+        batch = random_case(31, 20, d)
+        b = to_dev_batch(batch)
+        p = to_dev_params(params)
+        dims = ops.make_dims(b, H=d.H, L=d.L, da=d.da, A=d.A)
+        ws = ops.alloc_workspace(dims, dev())
+        scores = ops.forward(dims, b, p, ws)
+        lr = ops.ranking_loss(scores, batch["gt"].to(dev()).to(torch.int32))
+        g0 = {k: torch.full_like(v, float("nan")) for k, v in p.items()}
+        ops.backward(dims, b, p, ws, lr["dscores"], g0)
+        g12 = {k: torch.full_like(v, float("nan")) for k, v in p.items()}
+        ops.backward(dims, b, p, ws, lr["dscores"], g12, phase=1)
+        assert torch.isfinite(g12["answer_embedding"]).all() and torch.equal(g12["answer_embedding"], g0["answer_embedding"])
+        ops.backward(dims, b, p, ws, lr["dscores"], g12, phase=2)
+        for k in g0:
+            assert torch.equal(g0[k], g12[k]), k

@@ -627,8 +627,24 @@ int ncx_loss_rank(const float* scores, const int32_t* gt, int32_t B, int32_t K, 
     return NCX_OK;
 }
 
+static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, void* workspace,
+                         size_t workspace_bytes, const float* dscores, const ncx_grads* g, void* stream_, int phase);
+
 int ncx_backward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, void* workspace,
                  size_t workspace_bytes, const float* dscores, const ncx_grads* g, void* stream_) {
+    return backward_impl(dp, in, p, workspace, workspace_bytes, dscores, g, stream_, 0);
+}
+
+int ncx_backward_phase(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, void* workspace,
+                       size_t workspace_bytes, const float* dscores, const ncx_grads* g, int32_t phase, void* stream_) {
+    if (phase < 0 || phase > 2) return NCX_E_FLAGS;
+    return backward_impl(dp, in, p, workspace, workspace_bytes, dscores, g, stream_, phase);
+}
+
+// phase 0: everything.  phase 1: out / hidden layers / b1 and the answer_embedding gradient (complete when it
+// returns);  phase 2: linear_1.weight.  1 then 2 == 0 bit for bit (same kernels, the dGt problem launched alone).
+static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, void* workspace,
+                         size_t workspace_bytes, const float* dscores, const ncx_grads* g, void* stream_, int phase) {
     int rc = check_dims(dp);
     if (rc != NCX_OK) return rc;
     if (!in || !p || !workspace || !dscores || !g) return NCX_E_NULL;
@@ -667,7 +683,10 @@ int ncx_backward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, 
     // ---- out layer + last hidden layer's activation ------------------------------------------------
     const float* hL = (const float*)(ws + w.h[d.L - 1]);
     float* dpre = (float*)(ws + w.dpre[0]);
-    {
+    const bool do1 = phase != 2, do2 = phase != 1;
+    if (!do1) {                                       // phase 2: dpre_1 lives where phase 1 left it
+        dpre = (float*)(ws + w.dpre[(d.L - 1) & 1]);
+    } else {
         const long long total = (long long)M * H;
         hipLaunchKernelGGL(k_dpre_last, dim3((unsigned)cdiv(total, 1024)), dim3(256), 0, s, dscores, p->w_out, hL, dpre, total, H, dscale);
         NCX_HIP_TRY(hipGetLastError());
@@ -677,7 +696,7 @@ int ncx_backward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, 
     }
     // ---- hidden layers L..2 ---------------------------------------------------------------------------
     int cur = 0;
-    for (int l = d.L; l >= 2; --l) {
+    for (int l = d.L; l >= 2 && do1; --l) {
         const float* wl = l == 2 ? p->w2 : p->w3;
         float* gw = l == 2 ? g->w2 : g->w3;
         float* gb = l == 2 ? g->b2 : g->b3;
@@ -700,9 +719,11 @@ int ncx_backward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, 
         }
     }
     // ---- layer 1 ---------------------------------------------------------------------------------------
-    hipLaunchKernelGGL(k_rowgroup_sum, dim3((unsigned)cdiv((long long)d.B * H, 256)), dim3(256), 0, s, (const float*)dpre, d.B, d.K, H, dsh);
-    NCX_HIP_TRY(hipGetLastError());
-    rc = colsum(dsh, nullptr, d.B, H, g->b1); if (rc) return rc;
+    if (do1) {
+        hipLaunchKernelGGL(k_rowgroup_sum, dim3((unsigned)cdiv((long long)d.B * H, 256)), dim3(256), 0, s, (const float*)dpre, d.B, d.K, H, dsh);
+        NCX_HIP_TRY(hipGetLastError());
+        rc = colsum(dsh, nullptr, d.B, H, g->b1); if (rc) return rc;
+    }
     {   // dW1 = [dpre^T . candidate segments (+ dGt) | dSh^T . shared segments]: ONE grouped launch, per-problem
         // reduction extent (M rows of dpre vs B rows of dSh) and k-split
         GemmArgs a{}; a.mode = MODE_GROUP; a.M = H;
@@ -713,26 +734,32 @@ int ncx_backward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, 
         auto add_s = [&](const XDesc& x, float* out) {
             a.a[n] = x_plain(dsh, H, d.B, H); a.b[n] = x; a.klen[n] = d.B; a.out[n] = out; a.ldo[n] = din; a.n_cols[n] = x.cols;
             a.split[n] = u[U_DW1S].plan.split; ++n; };
-        add_c(x_gather(in->feats, d.dv, idx_k, M, d.dv), g->w1 + o.v_other, din);
-        if (d.flags & NCX_F_V_MULT) add_c(x_gather_mul(in->feats, d.dv, idx_k, idx_o, M, d.dv), g->w1 + o.v_mult, din);
-        add_c(x_plain(misc, d.K + 1, M, d.K + 1), g->w1 + o.v_dist, din);
-        add_c(x_plain(in->z_knns, d.dz, M, d.dz), g->w1 + o.z_other, din);
-        if (aemb) add_c(x_softmax(in->a_knns, d.A, mx, inv, M, d.A), dgt, d.A);
-        else      add_c(x_plain(in->a_knns, d.da, M, d.da), g->w1 + o.a_other, din);
-        add_s(x_gather(in->feats, d.dv, idx_ob, d.B, d.dv), g->w1 + o.v_orig);
-        add_s(x_plain(in->q_emb, d.dq, d.B, d.dq), g->w1 + o.q_emb);
-        add_s(x_plain(in->z_orig, d.dz, d.B, d.dz), g->w1 + o.z_orig);
-        add_s(aemb ? x_gather(p->answer_embedding, d.da, in->answer_aids, d.B, d.da) : x_plain(in->a_emb_gt, d.da, d.B, d.da),
-              g->w1 + o.a_gt);
+        // the dGt problem is what the answer_embedding gradient waits for: phase 1 launches it alone
+        const bool want_dgt = aemb && do1, want_rest = do2;
+        if (want_rest) {
+            add_c(x_gather(in->feats, d.dv, idx_k, M, d.dv), g->w1 + o.v_other, din);
+            if (d.flags & NCX_F_V_MULT) add_c(x_gather_mul(in->feats, d.dv, idx_k, idx_o, M, d.dv), g->w1 + o.v_mult, din);
+            add_c(x_plain(misc, d.K + 1, M, d.K + 1), g->w1 + o.v_dist, din);
+            add_c(x_plain(in->z_knns, d.dz, M, d.dz), g->w1 + o.z_other, din);
+            if (!aemb) add_c(x_plain(in->a_knns, d.da, M, d.da), g->w1 + o.a_other, din);
+        }
+        if (want_dgt) add_c(x_softmax(in->a_knns, d.A, mx, inv, M, d.A), dgt, d.A);
+        if (want_rest) {
+            add_s(x_gather(in->feats, d.dv, idx_ob, d.B, d.dv), g->w1 + o.v_orig);
+            add_s(x_plain(in->q_emb, d.dq, d.B, d.dq), g->w1 + o.q_emb);
+            add_s(x_plain(in->z_orig, d.dz, d.B, d.dz), g->w1 + o.z_orig);
+            add_s(aemb ? x_gather(p->answer_embedding, d.da, in->answer_aids, d.B, d.da) : x_plain(in->a_emb_gt, d.da, d.B, d.da),
+                  g->w1 + o.a_gt);
+        }
         a.nseg = n;
-        rc = run_gemm(U_DW1C, a, FORM_TN, u[U_DW1C].plan, slab, w.slab_bytes, nullptr, s); if (rc) return rc;
-        if (!(d.flags & NCX_F_V_MULT)) {
+        if (n > 0) { rc = run_gemm(U_DW1C, a, FORM_TN, u[U_DW1C].plan, slab, w.slab_bytes, nullptr, s); if (rc) return rc; }
+        if (!(d.flags & NCX_F_V_MULT) && do2) {
             hipLaunchKernelGGL(k_zero_cols, dim3((unsigned)cdiv((long long)H * d.dv, 256)), dim3(256), 0, s, g->w1 + o.v_mult, H, din, d.dv);
             NCX_HIP_TRY(hipGetLastError());
         }
     }
     if (aemb) {
-        {   // dE[a][j] = sum_n dGt[n][a] W1ak[n][j] + sum_n dGgt[n][a] W1agt[n][j],  dGgt = one-hot(aid)^T dSh
+        if (do1) {   // dE[a][j] = sum_n dGt[n][a] W1ak[n][j] + sum_n dGgt[n][a] W1agt[n][j],  dGgt = one-hot(aid)^T dSh
             NCX_HIP_TRY(hipMemsetAsync(dagt, 0, (size_t)H * d.A * 4, s));
             hipLaunchKernelGGL(k_scatter_dsh_by_answer, dim3(d.B), dim3(256), 0, s, (const float*)dsh, in->answer_aids, d.B, H, d.A, dagt);
             NCX_HIP_TRY(hipGetLastError());
@@ -742,13 +769,13 @@ int ncx_backward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, 
             a.out[0] = g->answer_embedding; a.ldo[0] = d.da; a.n_cols[0] = d.da;
             rc = run_gemm(U_DE, a, FORM_TN, u[U_DE].plan, slab, w.slab_bytes, nullptr, s); if (rc) return rc;
         }
-        {   // dW1[:, a_other][n][j] = sum_a dGt[n][a] E[a][j]
+        if (do2) {   // dW1[:, a_other][n][j] = sum_a dGt[n][a] E[a][j]
             GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = H;
             a.a[0] = x_plain(dgt, d.A, H, d.A); a.b[0] = x_plain(p->answer_embedding, d.da, d.A, d.da); a.klen[0] = d.A;
             a.out[0] = g->w1 + o.a_other; a.ldo[0] = din; a.n_cols[0] = d.da;
             rc = run_gemm(U_DW1AK, a, FORM_NN, u[U_DW1AK].plan, slab, w.slab_bytes, nullptr, s); if (rc) return rc;
         }
-    } else {
+    } else if (do1) {
         NCX_HIP_TRY(hipMemsetAsync(g->answer_embedding, 0, (size_t)d.A * d.da * 4, s));
     }
     return NCX_OK;

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libneuralcx_hip.so")
 NCX_F_V_MULT, NCX_F_V_DIST, NCX_F_V_RANK, NCX_F_A_EMB = 1, 2, 4, 8
 NCX_F_ALL = 15
 
-EXPORTS = ("ncx_input_size", "ncx_workspace_bytes", "ncx_forward", "ncx_loss_rank", "ncx_backward",
+EXPORTS = ("ncx_input_size", "ncx_workspace_bytes", "ncx_forward", "ncx_loss_rank", "ncx_backward", "ncx_backward_phase",
            "ncx_adam_step", "ncx_version", "ncx_profile_begin", "ncx_profile_end", "ncx_plan_query")
 
 
@@ -74,6 +74,9 @@ def lib():
     L.ncx_backward.restype = C.c_int
     L.ncx_backward.argtypes = [C.POINTER(NcxDims), C.POINTER(NcxInputs), C.POINTER(NcxParams), C.c_void_p,
                                C.c_size_t, C.c_void_p, C.POINTER(NcxGrads), C.c_void_p]
+    L.ncx_backward_phase.restype = C.c_int
+    L.ncx_backward_phase.argtypes = [C.POINTER(NcxDims), C.POINTER(NcxInputs), C.POINTER(NcxParams), C.c_void_p,
+                                     C.c_size_t, C.c_void_p, C.POINTER(NcxGrads), C.c_int32, C.c_void_p]
     L.ncx_adam_step.restype = C.c_int
     L.ncx_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float,
                                 C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]

@@ -122,9 +122,17 @@ class NeuralCXEngine:
         d = self._dims(batch, True, 1.0 / gb)
         scores = ops.forward(d, batch, self.params.fields(), self._ws)
         r = ops.ranking_loss(scores, gt, scale=1.0 / gb)
-        ops.backward(d, batch, self.params.fields(), self._ws, r["dscores"], self.grads.fields())
         if self.world_size > 1:
-            dp.allreduce_sum_(self.grads.flat, group=self.pg)                     # RCCL sum over xGMI
+            # answer_embedding is first in the flat buffer: its 19 MB all-reduce (RCCL over xGMI, NCCL's own stream)
+            # runs under the second half of backward; only the linear_1.weight bucket is exposed
+            n_emb = self.params.offsets["linear_1.weight"]
+            ops.backward(d, batch, self.params.fields(), self._ws, r["dscores"], self.grads.fields(), phase=1)
+            h1 = torch.distributed.all_reduce(self.grads.flat[:n_emb], group=self.pg, async_op=True)
+            ops.backward(d, batch, self.params.fields(), self._ws, r["dscores"], self.grads.fields(), phase=2)
+            h2 = torch.distributed.all_reduce(self.grads.flat[n_emb:], group=self.pg, async_op=True)
+            h1.wait(); h2.wait()
+        else:
+            ops.backward(d, batch, self.params.fields(), self._ws, r["dscores"], self.grads.fields())
         ops.adam_step(self.params.flat, self.grads.flat, self.exp_avg, self.exp_avg_sq, self.step_count, lr=self.lr)
         r["scores"] = scores
         return r

@@ -148,11 +148,17 @@ def forward(d: NcxDims, batch: Batch, params: Dict[str, torch.Tensor], ws: torch
 
 
 def backward(d: NcxDims, batch: Batch, params: Dict[str, torch.Tensor], ws: torch.Tensor, dscores: torch.Tensor,
-             grads: Dict[str, torch.Tensor]) -> None:
+             grads: Dict[str, torch.Tensor], phase: int = 0) -> None:
+    """phase 0: whole backward.  phase 1 / 2: first / second half (see ncx_backward_phase) for comm overlap."""
     p, n = _ws_ptr(ws)
     ins, ps, gs = batch.c_struct(), _params_struct(params, NcxParams), _params_struct(grads, NcxGrads)
-    _lib.check(_lib.lib().ncx_backward(C.byref(d), C.byref(ins), C.byref(ps), p, n,
-                                       _ptr(dscores, torch.float32, "dscores"), C.byref(gs), _stream()), "ncx_backward")
+    if phase == 0:
+        _lib.check(_lib.lib().ncx_backward(C.byref(d), C.byref(ins), C.byref(ps), p, n,
+                                           _ptr(dscores, torch.float32, "dscores"), C.byref(gs), _stream()), "ncx_backward")
+    else:
+        _lib.check(_lib.lib().ncx_backward_phase(C.byref(d), C.byref(ins), C.byref(ps), p, n,
+                                                 _ptr(dscores, torch.float32, "dscores"), C.byref(gs), int(phase), _stream()),
+                   "ncx_backward_phase")
 
 
 def ranking_loss(scores: torch.Tensor, gt: torch.Tensor, scale: float = 0.0, want_grad: bool = True):
