@@ -157,10 +157,12 @@ def main():
         prof = _lib.profile_end()
         c = eng.cfg
         M = args.batch * c["K"]
-        # algorithmic K-extent of the candidate segments (one-hot rank = 0 flops; the a_emb_other
-        # segment is consumed in its re-associated form softmax(a) . (E . W^T): A columns instead of da)
-        p_cols = 2 * c["dv"] + 1 + c["dz"] + c["A"]
-        flops_main = 2.0 * M * c["H"] * p_cols
+        # Algorithmic flops per launch (SURVEY 8d conventions: one-hot rank columns = 0 flops; the a_emb_other
+        # segment is consumed in its re-associated form softmax(a) . (E . W^T): A columns instead of da).
+        p_cols = 2 * c["dv"] + 1 + c["dz"] + c["A"]                     # candidate segments
+        s_cols = c["dv"] + c["dq"] + c["dz"] + c["da"]                  # per-triplet shared segments
+        flops = {"MAIN": 2.0 * M * c["H"] * p_cols,                     # h1 = candidates . W1 slices
+                 "DW1C": 2.0 * M * c["H"] * p_cols + 2.0 * args.batch * c["H"] * s_cols}   # all dW1 columns + dGt
         d0 = eng._dims(pool[0][0], True, 1.0 / gb)
         plans = {k: _lib.plan_query(d0, k) for k in ("MAIN", "DW1C")}
         names = {"MAIN": "seg_gemm NT %s (linear_1 candidate segments, fwd)" % plans["MAIN"]["tile"],
@@ -170,11 +172,11 @@ def main():
         dom = max(per, key=per.get) if per else None
         roof = None
         if dom:
-            ach = flops_main / (per[dom] * 1e-3) / 1e12
+            ach = flops[dom] / (per[dom] * 1e-3) / 1e12
             roof = dict(bound="mfma", kernel=names[dom], achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS,
                         unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
-                        launch_ms=round(per[dom], 4), algorithmic_gflop_per_launch=round(flops_main / 1e9, 3),
-                        other={k: dict(launch_ms=round(v, 4), tflops=round(flops_main / (v * 1e-3) / 1e12, 2),
+                        launch_ms=round(per[dom], 4), algorithmic_gflop_per_launch=round(flops[dom] / 1e9, 3),
+                        other={k: dict(launch_ms=round(v, 4), tflops=round(flops[k] / (v * 1e-3) / 1e12, 2),
                                        plan=plans[k]) for k, v in per.items()})
         out = dict(metric="VQA-CX triplets/sec (24 candidates each), NeuralCX training step",
                    value=round(gb * args.steps / dt, 1), unit="triplets/s", n_gpus=world, steps=args.steps,
