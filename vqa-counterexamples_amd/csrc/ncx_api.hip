@@ -349,9 +349,18 @@ static GemmPlan plan_from_tiles(int form, long long tiles_big, long long tiles_s
 }
 
 GemmPlan plan_gemm(int form, long long M, long long N, long long ksteps, bool allow_96) {
-    if (form == FORM_NT && allow_96 && M % 96 == 0 && N % 128 == 0 && (M / 96) * (N / 128) >= 192 &&
-        (M % 128 != 0 || cdiv(M, 128) * cdiv(N, 128) < 256)) {
-        GemmPlan p; p.cfg = CFG_96x128; p.split = 1; return p;
+    // Epilogue GEMMs (forward layers) never split; both big NT tiles run one workgroup per CU, so pick the one
+    // whose tile count fills whole rounds of CUs better (H=512: 384 tiles of 128x128 = 1.5 rounds, 512 of 96x128 = 2).
+    if (form == FORM_NT && allow_96 && M >= 96 && N >= 128) {
+        const double cus = (double)num_cus();
+        const double t128 = (double)(cdiv(M, 128) * cdiv(N, 128)), t96 = (double)(cdiv(M, 96) * cdiv(N, 128));
+        const double waste128 = (double)(cdiv(M, 128) * 128 * cdiv(N, 128) * 128) / (double)(M * N);
+        const double waste96 = (double)(cdiv(M, 96) * 96 * cdiv(N, 128) * 128) / (double)(M * N);
+        const double e128 = (t128 / cus) / (double)cdiv((long long)t128, (long long)cus) / waste128;
+        const double e96 = (t96 / cus) / (double)cdiv((long long)t96, (long long)cus) / waste96;
+        if (t96 >= 0.75 * cus || t128 >= 0.75 * cus) {
+            GemmPlan p; p.split = 1; p.cfg = e96 > e128 * 1.02 ? CFG_96x128 : CFG_128x128; return p;
+        }
     }
     const bool big_ok = M >= 96 && N >= 96;
     return plan_from_tiles(form, cdiv(M, 128) * cdiv(N, 128), cdiv(M, 64) * cdiv(N, 64), ksteps, big_ok);
