@@ -44,20 +44,23 @@ struct XDesc {
     int kind;
     int rows;
     int cols;
-    int pad_;
+    int idx_stride;      // idx[r * idx_stride] (1 = dense; K+1 picks column 0 of img_idx[B][K+1])
 };
 
 static inline XDesc x_plain(const float* base, long long ld, int rows, int cols) {
-    XDesc d{}; d.base = base; d.ld = ld; d.kind = X_PLAIN; d.rows = rows; d.cols = cols; return d;
+    XDesc d{}; d.base = base; d.ld = ld; d.kind = X_PLAIN; d.rows = rows; d.cols = cols; d.idx_stride = 1; return d;
 }
 static inline XDesc x_gather(const float* table, long long ld, const int* idx, int rows, int cols) {
-    XDesc d{}; d.base = table; d.ld = ld; d.idx = idx; d.kind = X_GATHER; d.rows = rows; d.cols = cols; return d;
+    XDesc d{}; d.base = table; d.ld = ld; d.idx = idx; d.kind = X_GATHER; d.rows = rows; d.cols = cols; d.idx_stride = 1; return d;
+}
+static inline XDesc x_gather_strided(const float* table, long long ld, const int* idx, int idx_stride, int rows, int cols) {
+    XDesc d = x_gather(table, ld, idx, rows, cols); d.idx_stride = idx_stride; return d;
 }
 static inline XDesc x_gather_mul(const float* table, long long ld, const int* idx, const int* idx2, int rows, int cols) {
-    XDesc d{}; d.base = table; d.ld = ld; d.idx = idx; d.idx2 = idx2; d.kind = X_GATHER_MUL; d.rows = rows; d.cols = cols; return d;
+    XDesc d{}; d.base = table; d.ld = ld; d.idx = idx; d.idx2 = idx2; d.kind = X_GATHER_MUL; d.rows = rows; d.cols = cols; d.idx_stride = 1; return d;
 }
 static inline XDesc x_softmax(const float* logits, long long ld, const float* mx, const float* inv, int rows, int cols) {
-    XDesc d{}; d.base = logits; d.ld = ld; d.mx = mx; d.inv = inv; d.kind = X_SOFTMAX; d.rows = rows; d.cols = cols; return d;
+    XDesc d{}; d.base = logits; d.ld = ld; d.mx = mx; d.inv = inv; d.kind = X_SOFTMAX; d.rows = rows; d.cols = cols; d.idx_stride = 1; return d;
 }
 
 constexpr int NCX_MAX_SEG = 10;
@@ -175,10 +178,10 @@ struct OpLoader {
                 const int rc = min(r, d.rows - 1);
                 rowmask |= (r < d.rows ? 1u : 0u) << i;
                 if (kind == X_GATHER) {
-                    p0[i] = d.base + (long long)d.idx[rc] * d.ld;
+                    p0[i] = d.base + (long long)d.idx[(long long)(rc) * d.idx_stride] * d.ld;
                 } else if (kind == X_GATHER_MUL) {
-                    p0[i] = d.base + (long long)d.idx[rc] * d.ld;
-                    p1[i] = d.base + (long long)d.idx2[rc] * d.ld;
+                    p0[i] = d.base + (long long)d.idx[(long long)(rc) * d.idx_stride] * d.ld;
+                    p1[i] = d.base + (long long)d.idx2[(long long)(rc) * d.idx_stride] * d.ld;
                 } else {
                     p0[i] = d.base + (long long)rc * d.ld;
                     if (kind == X_SOFTMAX) { mx[i] = d.mx[rc]; }
@@ -190,8 +193,8 @@ struct OpLoader {
     __device__ __forceinline__ void prefetch_rows(const XDesc& d, int k, int tid) {
         if (!COLK) {
             const int rc = min(k + (tid >> 3), d.rows - 1);
-            if (kind == X_GATHER || kind == X_GATHER_MUL) nidx0 = d.idx[rc];
-            if (kind == X_GATHER_MUL) nidx1 = d.idx2[rc];
+            if (kind == X_GATHER || kind == X_GATHER_MUL) nidx0 = d.idx[(long long)(rc) * d.idx_stride];
+            if (kind == X_GATHER_MUL) nidx1 = d.idx2[(long long)(rc) * d.idx_stride];
         }
     }
     __device__ __forceinline__ void issue(const XDesc& d, int k, int tid) {
@@ -276,8 +279,8 @@ struct OpLoader {
                 for (int i = 0; i < NV; ++i) v1[i] = *(const f32x4u*)(p1[0] + c + 32 * i);
             }
             // gather indices of this loader's next k-step
-            if (KIND == X_GATHER || KIND == X_GATHER_MUL) nidx0 = d.idx[min(r + idx_ahead, rows - 1)];
-            if (KIND == X_GATHER_MUL) nidx1 = d.idx2[min(r + idx_ahead, rows - 1)];
+            if (KIND == X_GATHER || KIND == X_GATHER_MUL) nidx0 = d.idx[(long long)(min(r + idx_ahead, rows - 1)) * d.idx_stride];
+            if (KIND == X_GATHER_MUL) nidx1 = d.idx2[(long long)(min(r + idx_ahead, rows - 1)) * d.idx_stride];
         }
     }
     template <int KIND>

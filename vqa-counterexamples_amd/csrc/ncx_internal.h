@@ -55,6 +55,7 @@ struct WsLayout {
     size_t partial;                     // column-sum partials [NCX_COLSUM_CHUNKS][H] x 2 + scalars
     size_t slab;                        // split-K slabs (max over all uses)
     size_t slab_bytes;
+    size_t slab2, slab2_bytes;          // slab of the GEMMs that run on the internal side stream
     size_t total;
 };
 constexpr int NCX_COLSUM_CHUNKS = 256;
