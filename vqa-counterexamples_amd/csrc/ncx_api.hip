@@ -218,6 +218,73 @@ __global__ __launch_bounds__(256) void k_sum_vec(const float* __restrict__ x, in
     if (threadIdx.x == 0) out[0] = sl[0] + sl[1] + sl[2] + sl[3];
 }
 
+// Backward prelude in one pass over h_L (thread = column n, block = a run of triplets):
+//   dpre[r][n] = gs[r] * w_out[n] * (h[r][n] > 0 ? scale : 0)                    (out + dropout + relu backward)
+//   partial_w[blk][n] = sum_r gs[r] h[r][n]    partial_b[blk] = sum_r gs[r]       (-> d out.weight, d out.bias)
+//   L == 1 only: dsh[b][n] = sum_k dpre[b*K+k][n],  partial_b1[blk][n] = sum_b dsh[b][n]   (-> d linear_1.bias)
+__global__ __launch_bounds__(256) void k_bwd_prelude(const float* __restrict__ gs, const float* __restrict__ w_out,
+                                                     const float* __restrict__ h, float* __restrict__ dpre,
+                                                     float* __restrict__ dsh, int B, int K, int H, float scale,
+                                                     float* __restrict__ partial_w, float* __restrict__ partial_b1,
+                                                     float* __restrict__ partial_b) {
+    const int blk = blockIdx.x, nblk = gridDim.x;
+    const int b0 = (int)((long long)B * blk / nblk), b1 = (int)((long long)B * (blk + 1) / nblk);
+    for (int n = threadIdx.x; n < H; n += 256) {
+        const float w = w_out[n];
+        float aw = 0.f, ab1 = 0.f;
+        for (int b = b0; b < b1; ++b) {
+            float ds = 0.f;
+            const long long r0 = (long long)b * K;
+            for (int k = 0; k < K; ++k) {
+                const float g = gs[r0 + k];
+                const float hv = h[(r0 + k) * H + n];
+                const float dp = hv > 0.f ? g * w * scale : 0.f;
+                dpre[(r0 + k) * H + n] = dp;
+                aw += g * hv;
+                ds += dp;
+            }
+            if (dsh) { dsh[(long long)b * H + n] = ds; ab1 += ds; }
+        }
+        partial_w[(long long)blk * H + n] = aw;
+        if (dsh) partial_b1[(long long)blk * H + n] = ab1;
+    }
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (long long r = (long long)b0 * K; r < (long long)b1 * K; ++r) s += gs[r];
+        partial_b[blk] = s;
+    }
+}
+// out_w[n] = sum_blk partial_w[blk][n]; out_b1[n] likewise (nullable); out_b[0] = sum_blk partial_b[blk]
+__global__ __launch_bounds__(256) void k_bwd_prelude_finish(const float* __restrict__ partial_w, const float* __restrict__ partial_b1,
+                                                            const float* __restrict__ partial_b, int nblk, int H,
+                                                            float* __restrict__ out_w, float* __restrict__ out_b1,
+                                                            float* __restrict__ out_b) {
+    __shared__ float red[32][9];
+    const int c = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const int which = blockIdx.y;                                   // 0: out.weight, 1: linear_1.bias
+    const float* part = which == 0 ? partial_w : partial_b1;
+    float* out = which == 0 ? out_w : out_b1;
+    if (!out) return;
+    const int n = blockIdx.x * 8 + c;
+    float s = 0.f;
+    if (n < H) for (int ch = g; ch < nblk; ch += 32) s += part[(long long)ch * H + n];
+    red[g][c] = s;
+    __syncthreads();
+    if (g == 0 && n < H) {
+        float t = 0.f;
+        for (int i = 0; i < 32; ++i) t += red[i][c];
+        out[n] = t;
+    }
+    if (which == 0 && blockIdx.x == 0) {              // d out.bias: nblk <= 256 partials, fixed-order tree
+        __shared__ float sb[4];
+        float v = (int)threadIdx.x < nblk ? partial_b[threadIdx.x] : 0.f;
+        v = wave_sum(v);
+        if ((threadIdx.x & 63) == 0) sb[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) out_b[0] = (sb[0] + sb[1]) + (sb[2] + sb[3]);
+    }
+}
+
 // dsh[b][n] = sum_k dpre[b*K + k][n]
 __global__ __launch_bounds__(256) void k_rowgroup_sum(const float* __restrict__ dpre, int B, int K, int H,
                                                       float* __restrict__ dsh) {
@@ -443,7 +510,7 @@ WsLayout ws_layout(const ncx_dims& d) {
     w.dsh = take((size_t)d.B * H * 4);
     w.dgt = take(H * d.A * 4);
     w.dagt = take(H * d.A * 4);                         // dGgt[H][A] = one-hot(aid)^T dSh, transposed
-    w.partial = take((size_t)NCX_COLSUM_CHUNKS * H * 4 * 2 + 256);
+    w.partial = take((size_t)NCX_COLSUM_CHUNKS * H * 4 * 2 + (size_t)NCX_COLSUM_CHUNKS * 4 + 256);
     GemmUse u[U_COUNT];
     list_uses(d, u);
     long long slab = 0;
@@ -748,11 +815,17 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
     if (!do1) {                                       // phase 2: dpre_1 lives where phase 1 left it
         dpre = (float*)(ws + w.dpre[(d.L - 1) & 1]);
     } else {
-        const long long total = (long long)M * H;
-        hipLaunchKernelGGL(k_dpre_last, dim3((unsigned)cdiv(total, 1024)), dim3(256), 0, s, dscores, p->w_out, hL, dpre, total, H, dscale);
+        // one pass: dpre_L, d out.weight / d out.bias partials, and for L == 1 also dSh + d linear_1.bias partials
+        const int nblk = d.B < NCX_COLSUM_CHUNKS ? d.B : NCX_COLSUM_CHUNKS;
+        float* part_w = partial;
+        float* part_b1 = partial + (size_t)NCX_COLSUM_CHUNKS * H;
+        float* part_b = partial + (size_t)NCX_COLSUM_CHUNKS * H * 2;
+        const bool fuse_l1 = d.L == 1;
+        hipLaunchKernelGGL(k_bwd_prelude, dim3(nblk), dim3(256), 0, s, dscores, p->w_out, hL, dpre, fuse_l1 ? dsh : (float*)nullptr,
+                           d.B, d.K, H, dscale, part_w, part_b1, part_b);
         NCX_HIP_TRY(hipGetLastError());
-        rc = colsum(hL, dscores, M, H, g->w_out); if (rc) return rc;
-        hipLaunchKernelGGL(k_sum_vec, dim3(1), dim3(256), 0, s, dscores, M, g->b_out);
+        hipLaunchKernelGGL(k_bwd_prelude_finish, dim3((unsigned)cdiv(H, 8), fuse_l1 ? 2 : 1), dim3(256), 0, s, (const float*)part_w,
+                           (const float*)part_b1, (const float*)part_b, nblk, H, g->w_out, fuse_l1 ? g->b1 : (float*)nullptr, g->b_out);
         NCX_HIP_TRY(hipGetLastError());
     }
     // ---- hidden layers L..2 ---------------------------------------------------------------------------
@@ -780,7 +853,7 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
         }
     }
     // ---- layer 1 ---------------------------------------------------------------------------------------
-    if (do1) {
+    if (do1 && d.L >= 2) {                              // (L == 1: already produced by k_bwd_prelude)
         hipLaunchKernelGGL(k_rowgroup_sum, dim3((unsigned)cdiv((long long)d.B * H, 256)), dim3(256), 0, s, (const float*)dpre, d.B, d.K, H, dsh);
         NCX_HIP_TRY(hipGetLastError());
         rc = colsum(dsh, nullptr, d.B, H, g->b1); if (rc) return rc;
