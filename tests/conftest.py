@@ -14,6 +14,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
+    # the C-ABI tests need the built library; hipcc cross-compiles gfx950 without a GPU (a few seconds)
+    lib = os.path.join(PKG, "lib", "libneuralcx_hip.so")
+    if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
+        import subprocess
+        subprocess.run(["make", "-j4", "-C", PKG], check=False, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
 def _has_gpu():

@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
         if constexpr (DEPTH2) fast_run2(akind_c, bkind_c, nfast, buf);
         else fast_run(akind_c, bkind_c, nfast, buf);
     };
-    const bool tile_interior = m0 + BM <= M && n0 + BN <= N;
+    const bool tile_interior = m0 + BM <= M && n0 + BN <= N && args.pad_ == 0;      // pad_ != 0: force the generic path (diagnostics)
 
     // ---- main loop ------------------------------------------------------------------------------
     if (step_begin < step_end) {
