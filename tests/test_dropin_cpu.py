@@ -147,3 +147,31 @@ def test_dp2_gloo_matches_single_process_gradient():
     assert n == batch["gt"].shape[0]
     assert abs(l / n - float(g["loss"])) < 1e-5
     assert np.abs(flat - ref).max() <= 1e-6 * max(np.abs(ref).max(), 1.0)
+
+
+def test_examples_to_arrays_matches_reference_semantics():
+    """getDataFromBatch (counterexamples.py:519-547): indices of [image] + knns, wids, aids, comp knn_index."""
+    import random
+    from neuralcx.data import batchify, examples_to_arrays
+    names = ["img%03d" % i for i in range(40)]
+    n2i = {n: 7 * i % 40 for i, n in enumerate(names)}
+    rng = random.Random(0)
+    exs = []
+    for e in range(10):
+        knns = rng.sample(names, 24)
+        exs.append(dict(image_name=names[e], knns=knns, comp=dict(knn_index=rng.randrange(24)),
+                        question_wids=[rng.randrange(1, 30) for _ in range(26)], answer_aid=rng.randrange(2000)))
+    idx, wids, aids, comp = examples_to_arrays(exs, n2i)
+    assert idx.shape == (10, 25) and idx.dtype == np.int32 and wids.shape == (10, 26)
+    for i, ex in enumerate(exs):
+        assert idx[i, 0] == n2i[ex["image_name"]] and list(idx[i, 1:]) == [n2i[n] for n in ex["knns"]]
+        assert aids[i] == ex["answer_aid"] and comp[i] == ex["comp"]["knn_index"]
+    feats = np.arange(40 * 3, dtype=np.float32).reshape(40, 3)
+    dense = np.array([feats[r] for r in idx])                   # what the reference materialises (:540)
+    assert dense.shape == (10, 25, 3) and (dense[:, 0] == feats[idx[:, 0]]).all()
+    pidx, _, _, _ = examples_to_arrays(exs, n2i, pairwise=True, rng=random.Random(1))
+    assert pidx.shape == (10, 3)
+    for i, ex in enumerate(exs):
+        assert pidx[i, 1] == n2i[ex["knns"][ex["comp"]["knn_index"]]] and pidx[i, 2] != pidx[i, 1]
+    b = batchify(list(range(10)), 4, shuffle=False)
+    assert b == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]]

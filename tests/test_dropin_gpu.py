@@ -133,3 +133,69 @@ def test_cli_synthetic_smoke(tmp_path, capsys):
         info = torch.load(os.path.join(base, sub, "info.ckpt"))
         assert {"loss", "recall"} <= set(info[-1])
     assert os.path.exists(os.path.join(base, "final_results.txt"))
+
+
+def _dp_gpu_worker(rank, world, port, q):
+    import os, sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from conftest import PKG, ROOT
+    sys.path[:0] = [ROOT, PKG, os.path.join(ROOT, "tests")]
+    import torch.distributed as dist
+    from neuralcx import dp, ops
+    from neuralcx.engine import NeuralCXEngine
+    dp.init_distributed(backend="gloo")
+    d = orc.Dims(dv=96, dq=64, dz=24, A=40, H=64, L=2)
+    Bg = 12
+    batch = _dp_batch(d, Bg)
+    params = orc.init_params(d, seed=4, gain=2.0)
+    eng = NeuralCXEngine(K=d.K, dv=d.dv, dq=d.dq, dz=d.dz, da=d.da, A=d.A, H=d.H, L=d.L, drop_p=0.0, lr=1e-3, device=DEV,
+                         world_size=world)
+    eng.rank = rank
+    eng.load_state(params)
+    ids = dp.shard(list(range(Bg)), rank, world)
+    sub = {k: v[ids] for k, v in batch.items()}
+    b = ops.Batch.from_dense(*[sub[k].to(DEV) for k in ("image_features", "q_emb", "z_orig", "z_knns", "a_knns", "answer_aids")])
+    r = eng.train_step(b, sub["gt"].to(DEV).to(torch.int32), global_batch=Bg)
+    torch.cuda.synchronize()
+    loss = torch.tensor([float(r["loss"])], dtype=torch.float64)
+    dist.all_reduce(loss)                                           # sum of the 1/B_global-scaled local losses
+    if rank == 0:
+        out = {k: v.cpu().numpy() for k, v in eng.grads.views.items()}     # all-reduced gradient of the global batch
+        out["__loss__"] = float(loss)
+        q.put(out)
+    dist.barrier(); dist.destroy_process_group()
+
+
+def _dp_batch(d, B):
+    rng = np.random.default_rng(3)
+    t = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+    return dict(image_features=t(np.abs(rng.standard_normal((B, d.K + 1, d.dv))) * 0.45), q_emb=t(rng.standard_normal((B, d.dq)) * 0.3),
+                z_orig=t(rng.standard_normal((B, d.dz))), z_knns=t(rng.standard_normal((B, d.K, d.dz))),
+                a_knns=t(rng.standard_normal((B, d.K, d.A)) * 2), answer_aids=torch.from_numpy(rng.integers(0, d.A, size=B)),
+                gt=torch.from_numpy(rng.integers(0, d.K, size=B)))
+
+
+def test_dp2_hip_engine_equals_dp1():
+    """SURVEY 8e: DP-R == DP-1 at the same global batch.  Two gloo ranks share the card (RCCL needs one GPU per rank);
+    each runs the HIP engine on its shard with loss_scale = 1/B_global, phased backward + async all-reduce, Adam."""
+    import torch.multiprocessing as mp
+    from neuralcx import ops
+    from neuralcx.engine import NeuralCXEngine
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + os.getpid() % 200
+    procs = [ctx.Process(target=_dp_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    dp2 = q.get(timeout=240)
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    d = orc.Dims(dv=96, dq=64, dz=24, A=40, H=64, L=2)
+    batch = _dp_batch(d, 12)
+    eng = NeuralCXEngine(K=d.K, dv=d.dv, dq=d.dq, dz=d.dz, da=d.da, A=d.A, H=d.H, L=d.L, drop_p=0.0, lr=1e-3, device=DEV)
+    eng.load_state(orc.init_params(d, seed=4, gain=2.0))
+    b = ops.Batch.from_dense(*[batch[k].to(DEV) for k in ("image_features", "q_emb", "z_orig", "z_knns", "a_knns", "answer_aids")])
+    r = eng.train_step(b, batch["gt"].to(DEV).to(torch.int32))
+    assert abs(dp2.pop("__loss__") - float(r["loss"])) <= 1e-5
+    for k, v in eng.grads.views.items():
+        ref = v.cpu().numpy()
+        assert np.abs(dp2[k] - ref).max() <= 1e-5 * max(np.abs(ref).max(), GRAD_FLOOR), k      # summation order only
