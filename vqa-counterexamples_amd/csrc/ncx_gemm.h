@@ -322,6 +322,37 @@ struct OpLoader {
     }
 };
 
+// XCD-aware workgroup order inside one problem.  Workgroups are dealt round-robin over the 8 XCDs (id % 8), each
+// with a private L2.  The tiles along the SHORT tile dimension ("minor": the 2 N-tiles of a forward row block, the 4
+// M-tiles of a weight-gradient column block) all stream the same expensive operand rows (gathered features,
+// logits), so they are placed 8 ids apart: same XCD, dispatched together -> one HBM/MALL fetch instead of one
+// per sharer.  Within a group of 8 consecutive ids the major tile varies first (same k-chunk z): those share the
+// cheap operand (weights / dpre chunk).  Pure permutation: any placement is correct, this one is fast.
+struct WgMap {
+    int tiles_m, tiles_n, S;
+    __host__ __device__ bool minor_n() const { return tiles_n <= tiles_m; }
+    __host__ __device__ int mc() const { return minor_n() ? tiles_n : tiles_m; }       // minor count
+    __host__ __device__ int jt() const { return minor_n() ? tiles_m : tiles_n; }       // major tiles
+    // local workgroup id -> (tm, tn, z)
+    __host__ __device__ void decode(int lw, int& tm, int& tn, int& z) const {
+        const int m = mc(), J = jt() * S, full = (J / 8) * 8;
+        int mi, q;
+        if (lw < full * m) { const int blk = lw / (8 * m), rem = lw - blk * 8 * m; mi = rem / 8; q = blk * 8 + (rem & 7); }
+        else { const int t = lw - full * m, r = J - full; mi = t / r; q = full + t - mi * r; }
+        z = q / jt();
+        const int major = q - z * jt();
+        tm = minor_n() ? major : mi; tn = minor_n() ? mi : major;
+    }
+    // (tm, tn, z) -> local workgroup id (slab slot of the partial tile)
+    __host__ __device__ int encode(int tm, int tn, int z) const {
+        const int m = mc(), J = jt() * S, full = (J / 8) * 8;
+        const int mi = minor_n() ? tn : tm, major = minor_n() ? tm : tn;
+        const int q = z * jt() + major;
+        if (q < full) return (q / 8) * 8 * m + mi * 8 + (q & 7);
+        return full * m + mi * (J - full) + (q - full);
+    }
+};
+
 template <int BM, int BN, bool A_COLK, bool B_COLK>
 struct GemmCfg {
     static constexpr int BK = GEMM_BK;
@@ -365,18 +396,18 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
     const int M = args.M;
     f32x4 acc[WM][WN];
     // ---- which problem / tile / k-chunk -------------------------------------------------------------
-    // Workgroups of problem p are numbered tile-major, chunk-minor: w = wg0[p] + tile*S + z.  All chunks z of
-    // different tiles advance through the same k range together and share their operand rows in L2.
+    // Workgroups of problem p: w = wg0[p] + WgMap::encode(tm, tn, z) (XCD-aware order, see WgMap).
     int prob = 0, lw = blockIdx.x;
     if (args.mode == MODE_GROUP) {
         while (prob + 1 < args.nseg && lw >= args.wg0[prob + 1]) ++prob;
         lw -= args.wg0[prob];
     }
     const int S = args.split[prob] > 1 ? args.split[prob] : 1;
-    const int tile = lw / S, z = lw - tile * S;
     const int N = args.n_cols[prob];
-    const int tiles_n = (N + BN - 1) / BN;
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const WgMap wmap{(M + BM - 1) / BM, (N + BN - 1) / BN, S};
+    int tm, tn, z;
+    wmap.decode(lw, tm, tn, z);
+    const int m0 = tm * BM, n0 = tn * BN;
     const int first_seg = args.mode == MODE_GROUP ? prob : 0;
     const int last_seg  = args.mode == MODE_GROUP ? prob + 1 : args.nseg;
     int total_steps = 0;
@@ -725,8 +756,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
     }
 }
 
-// Split fix-up: output tile t of problem p = sum of its S partial tiles (slab slots wg0[p] + t*S + z, z ascending:
-// deterministic) + optional bias, scattered to the problem's output with bounds.  Unsplit problems are skipped.
+// Split fix-up: output tile t of problem p = sum of its S partial tiles (slab slots wg0[p] + WgMap::encode(tm,tn,z),
+// z ascending: deterministic) + optional bias, scattered to the problem's output with bounds.  Unsplit problems are skipped.
 struct FixupArgs {
     float* out[NCX_MAX_SEG]; long long ldo[NCX_MAX_SEG]; int n_cols[NCX_MAX_SEG]; int split[NCX_MAX_SEG];
     int tile0[NCX_MAX_SEG + 1]; int wg0[NCX_MAX_SEG + 1];
@@ -752,8 +783,9 @@ __global__ __launch_bounds__(256) void split_fixup_kernel(const FixupArgs a) {
     f32x4 s[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* src = a.slab + ((long long)a.wg0[prob] + (long long)tile * S) * (BM * BN) + threadIdx.x * 4;
-    for (int z = 0; z < S; ++z, src += BM * BN) {
+    const WgMap wmap{(a.M + BM - 1) / BM, tiles_n, S};
+    for (int z = 0; z < S; ++z) {                      // k-chunk order: deterministic
+        const float* src = a.slab + ((long long)a.wg0[prob] + wmap.encode(tile / tiles_n, tile % tiles_n, z)) * (BM * BN) + threadIdx.x * 4;
 #pragma unroll
         for (int i = 0; i < E; ++i) s[i] += *(const f32x4*)(src + i * 1024);
     }
