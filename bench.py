@@ -173,8 +173,14 @@ def main():
         roof = None
         if dom:
             ach = flops[dom] / (per[dom] * 1e-3) / 1e12
+            # HBM bytes per launch of that kernel from the committed PMC passes (collected offline as the guide
+            # prescribes: separate --pmc runs, FETCH_SIZE x2 on gfx950); only valid for the default workload
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+            if os.path.exists(tpath) and (args.batch, c["K"], c["H"], c["L"]) == (512, 24, 256, 1):
+                traffic = json.load(open(tpath)).get(dom, {}).get("bytes_per_launch")
             roof = dict(bound="mfma", kernel=names[dom], achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS,
-                        unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                        unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
                         launch_ms=round(per[dom], 4), algorithmic_gflop_per_launch=round(flops[dom] / 1e9, 3),
                         other={k: dict(launch_ms=round(v, 4), tflops=round(flops[k] / (v * 1e-3) / 1e12, 2),
                                        plan=plans[k]) for k, v in per.items()})
