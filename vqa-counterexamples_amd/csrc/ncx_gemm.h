@@ -91,6 +91,8 @@ struct GemmArgs {
     int   tile0[NCX_MAX_SEG + 1];// first linear tile id of problem i           (filled by the launcher)
     int   wg0[NCX_MAX_SEG + 1];  // first workgroup id of problem i = sum tiles*split (filled by the launcher)
     int   mode, nseg, M, pad_;
+    int   total_wgs;             // work items (filled by the launcher); the grid may be smaller: persistent loop
+    int   pad2_;
     float* slab;                 // [workgroups][BM*BN] partial tiles of the split problems
     EpiArgs epi;
 };
@@ -395,9 +397,13 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
 
     const int M = args.M;
     f32x4 acc[WM][WN];
+  // Optional persistent loop (NCX_PERSISTENT=1; default: one workgroup per item): the grid holds at most one workgroup per resident slot (a multiple of 8, so item % 8 -- the XCD
+  // affinity WgMap is built on -- is the same for every item of a workgroup); a slot then never idles between the
+  // exit of one short workgroup and the dispatch of the next.
+  for (int item = blockIdx.x; item < args.total_wgs; item += gridDim.x) {
     // ---- which problem / tile / k-chunk -------------------------------------------------------------
-    // Workgroups of problem p: w = wg0[p] + WgMap::encode(tm, tn, z) (XCD-aware order, see WgMap).
-    int prob = 0, lw = blockIdx.x;
+    // Work items of problem p: w = wg0[p] + WgMap::encode(tm, tn, z) (XCD-aware order, see WgMap).
+    int prob = 0, lw = item;
     if (args.mode == MODE_GROUP) {
         while (prob + 1 < args.nseg && lw >= args.wg0[prob + 1]) ++prob;
         lw -= args.wg0[prob];
@@ -730,7 +736,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
     // ---- epilogue -------------------------------------------------------------------------------
     if (S > 1) {
         // partial tile -> this workgroup's slab slot (whole padded tile: padded operands contribute zeros)
-        float* slot = args.slab + (long long)blockIdx.x * (BM * BN);
+        float* slot = args.slab + (long long)item * (BM * BN);
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -738,7 +744,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
                     slot[trow(i, lk * 4 + q) * BN + tcol(j, li)] = acc[i][j][q];
-        return;
+        __syncthreads();                    // the LDS tiles are reused by the next item
+        continue;
     }
     float* out = args.out[args.mode == MODE_GROUP ? prob : 0];
     const long long ldo = args.ldo[args.mode == MODE_GROUP ? prob : 0];
@@ -754,6 +761,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
             }
         }
     }
+    __syncthreads();
+  }   // persistent loop
 }
 
 // Split fix-up: output tile t of problem p = sum of its S partial tiles (slab slots wg0[p] + WgMap::encode(tm,tn,z),
@@ -820,6 +829,20 @@ static inline long long gemm_layout(GemmArgs& args, int BM, int BN, bool* any_sp
     return wgs;
 }
 
+// Resident workgroups per CU of an instantiation (registers / LDS), for the planner; 2 when no device is present.
+template <int BM, int BN, bool A_COLK, bool B_COLK>
+static inline int seg_gemm_occupancy() {
+    typedef GemmCfg<BM, BN, A_COLK, B_COLK> Cfg;
+    int n = 0;
+    (void)hipFuncSetAttribute((const void*)seg_gemm_kernel<BM, BN, A_COLK, B_COLK>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, seg_gemm_kernel<BM, BN, A_COLK, B_COLK>, 256, Cfg::LDS_BYTES) != hipSuccess || n < 1) {
+        (void)hipGetLastError();
+        n = 2;
+    }
+    return n;
+}
+
 template <int BM, int BN, bool A_COLK, bool B_COLK>
 static inline hipError_t launch_seg_gemm(GemmArgs& args, hipStream_t stream) {
     typedef GemmCfg<BM, BN, A_COLK, B_COLK> Cfg;
@@ -833,7 +856,22 @@ static inline hipError_t launch_seg_gemm(GemmArgs& args, hipStream_t stream) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((seg_gemm_kernel<BM, BN, A_COLK, B_COLK>), dim3((unsigned)wgs), dim3(256), Cfg::LDS_BYTES, stream, args);
+    args.total_wgs = (int)wgs;
+    long long grid = wgs;
+    {   // persistent grid for many-short-workgroup launches: one workgroup per resident slot
+        static int slots = 0;
+        if (!slots) {
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) { (void)hipGetLastError(); cus = 256; }
+            slots = seg_gemm_occupancy<BM, BN, A_COLK, B_COLK>() * cus;
+            slots -= slots % 8;
+        }
+        // Measured (grouped dW1, 5856 items on 768 slots): 0.526 ms persistent vs 0.474 ms with one workgroup per
+        // item -- the hardware dispatcher balances the unequal items better than a static stride.  Opt-in only.
+        const char* pe = getenv("NCX_PERSISTENT");
+        if (pe && atoi(pe) && wgs > 2 * slots) grid = slots;
+    }
+    hipLaunchKernelGGL((seg_gemm_kernel<BM, BN, A_COLK, B_COLK>), dim3((unsigned)grid), dim3(256), Cfg::LDS_BYTES, stream, args);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !any_split) return e;
     FixupArgs f{};
@@ -843,20 +881,6 @@ static inline hipError_t launch_seg_gemm(GemmArgs& args, hipStream_t stream) {
     f.bias = args.epi.bias; f.slab = args.slab; f.mode = args.mode; f.nseg = args.nseg; f.M = args.M;
     hipLaunchKernelGGL((split_fixup_kernel<BM, BN>), dim3(args.tile0[np]), dim3(256), 0, stream, f);
     return hipGetLastError();
-}
-
-// Resident workgroups per CU of an instantiation (registers / LDS), for the planner; 2 when no device is present.
-template <int BM, int BN, bool A_COLK, bool B_COLK>
-static inline int seg_gemm_occupancy() {
-    typedef GemmCfg<BM, BN, A_COLK, B_COLK> Cfg;
-    int n = 0;
-    (void)hipFuncSetAttribute((const void*)seg_gemm_kernel<BM, BN, A_COLK, B_COLK>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, seg_gemm_kernel<BM, BN, A_COLK, B_COLK>, 256, Cfg::LDS_BYTES) != hipSuccess || n < 1) {
-        (void)hipGetLastError();
-        n = 2;
-    }
-    return n;
 }
 
 // Tile geometry of a config, for the planner.
