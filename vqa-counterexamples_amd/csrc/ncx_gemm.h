@@ -788,26 +788,19 @@ __global__ __launch_bounds__(256) void split_fixup_kernel(const FixupArgs a) {
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     float* out = a.out[prob];
     const long long ldo = a.ldo[prob];
-    constexpr int E = BM * BN / 1024;                 // float4 per thread
-    f32x4 s[E];
-#pragma unroll
-    for (int i = 0; i < E; ++i) s[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // one float4 per thread: blockIdx.y picks which 1024-element slice of the tile (BM*BN/1024 slices) -- small
+    // problems have few tiles, so the slices are spread over blocks for memory-level parallelism
+    const int e = blockIdx.y * 1024 + threadIdx.x * 4;
+    f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
     const WgMap wmap{(a.M + BM - 1) / BM, tiles_n, S};
-    for (int z = 0; z < S; ++z) {                      // k-chunk order: deterministic
-        const float* src = a.slab + ((long long)a.wg0[prob] + wmap.encode(tile / tiles_n, tile % tiles_n, z)) * (BM * BN) + threadIdx.x * 4;
+    for (int z = 0; z < S; ++z)                        // k-chunk order: deterministic
+        acc4 += *(const f32x4*)(a.slab + ((long long)a.wg0[prob] + wmap.encode(tile / tiles_n, tile % tiles_n, z)) * (BM * BN) + e);
+    const int gr = m0 + e / BN, c = e % BN;
+    if (gr < a.M) {
 #pragma unroll
-        for (int i = 0; i < E; ++i) s[i] += *(const f32x4*)(src + i * 1024);
-    }
-#pragma unroll
-    for (int i = 0; i < E; ++i) {
-        const int e = i * 1024 + threadIdx.x * 4;
-        const int gr = m0 + e / BN, c = e % BN;
-        if (gr < a.M) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int gc = n0 + c + j;
-                if (gc < N) out[(long long)gr * ldo + gc] = s[i][j] + (a.bias ? a.bias[gc] : 0.f);
-            }
+        for (int j = 0; j < 4; ++j) {
+            const int gc = n0 + c + j;
+            if (gc < N) out[(long long)gr * ldo + gc] = acc4[j] + (a.bias ? a.bias[gc] : 0.f);
         }
     }
 }
@@ -879,7 +872,7 @@ static inline hipError_t launch_seg_gemm(GemmArgs& args, hipStream_t stream) {
     for (int i = 0; i < np; ++i) { f.out[i] = args.out[i]; f.ldo[i] = args.ldo[i]; f.n_cols[i] = args.n_cols[i]; f.split[i] = args.split[i]; }
     for (int i = 0; i <= np; ++i) { f.tile0[i] = args.tile0[i]; f.wg0[i] = args.wg0[i]; }
     f.bias = args.epi.bias; f.slab = args.slab; f.mode = args.mode; f.nseg = args.nseg; f.M = args.M;
-    hipLaunchKernelGGL((split_fixup_kernel<BM, BN>), dim3(args.tile0[np]), dim3(256), 0, stream, f);
+    hipLaunchKernelGGL((split_fixup_kernel<BM, BN>), dim3(args.tile0[np], BM * BN / 1024), dim3(256), 0, stream, f);
     return hipGetLastError();
 }
 
