@@ -146,6 +146,31 @@ int ncx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   float lr, float beta1, float beta2, float eps, int32_t step, float grad_scale,
                   void* stream);
 
+/* ---- the frozen VQA producer upstream of NeuralCX -----------------------------------------
+ * Replaces CXModelBase.vqa_forward (vqa/models/cx.py:64-104) for the MutanNoAtt model in eval mode:
+ * MutanFusion.forward (vqa/models/fusion.py:78-121: linear_v/linear_q + activation, R x {linear_hv_i, linear_hq_i,
+ * hadamard}, sum) and AbstractNoAtt._classif (vqa/models/noatt.py:24-29) on the original + K candidate images.
+ * The question branch is evaluated once per question (the reference duplicates q K+1 times first, cx.py:83-87), the
+ * image gather is folded into linear_v, and the R rank-1 terms are folded inside ONE chained GEMM.  q_emb comes
+ * from the question encoder (seq2vec), which stays on the PyTorch side. */
+typedef struct ncx_mutan_params {
+    const float* wv;  const float* bv;    /* fusion.linear_v.weight [dhv, dv], .bias [dhv]                       */
+    const float* wq;  const float* bq;    /* fusion.linear_q.weight [dhq, dq], .bias [dhq]                       */
+    const float* whv; const float* bhv;   /* fusion.list_linear_hv.{0..R-1} stacked: [R*dz, dhv], [R*dz]         */
+    const float* whq; const float* bhq;   /* fusion.list_linear_hq.{0..R-1} stacked: [R*dz, dhq], [R*dz]         */
+    const float* wc;  const float* bc;    /* linear_classif.weight [A, dz], .bias [A]                            */
+    int32_t dhv, dhq, R;                  /* R <= 10                                                             */
+    int32_t act_v, act_q;                 /* activation_v / activation_q: 0 none, 2 tanh                         */
+} ncx_mutan_params;
+
+size_t ncx_vqa_workspace_bytes(const ncx_dims* d, const ncx_mutan_params* m);
+
+/* z_orig [B,dz], z_knns [B,K,dz], a_knns [B,K,A] (logits), a_orig [B,A] (nullable: NeuralModel never reads it).
+ * Uses d->B, K, dv, dq, dz, A, n_img only. */
+int ncx_vqa_forward(const ncx_dims* d, const float* feats, const int32_t* img_idx, const float* q_emb,
+                    const ncx_mutan_params* m, void* workspace, size_t workspace_bytes,
+                    float* z_orig, float* z_knns, float* a_knns, float* a_orig, void* stream);
+
 /* ---- diagnostics (bench.py / tests only; the only process-global state, off by default) --------------
  * GEMM ids: 0 Gt = W1[:,a_other].E^T, 1 Sh (shared segments), 2 MAIN (candidate segments, the dominant
  * forward kernel), 3 hidden layer l>=2 forward, 4 dW1 candidate columns (+dGt; the dominant backward

@@ -196,6 +196,11 @@ def run_case(name, dims, H, L, B, seed, spec_over=None, scale_feat=0.45, full_gr
             out["gradval/" + n] = flat[ii].copy()
             if flat.size <= 4096:
                 out["grad/" + n] = g.copy()
+    if full_grads:      # G6 (small cases): the frozen MUTAN weights, so vqa_forward itself can be checked (cx.py:64-104)
+        for n, p in m.named_parameters():
+            if n.startswith("vqa_model.fusion.") or n.startswith("vqa_model.linear_classif."):
+                out["vqa/" + n[len("vqa_model."):]] = p.detach().numpy().copy()
+        out["vqa_R"] = np.int64(len(vqa.fusion.list_linear_hv))
     out["weight_seed"] = np.int64(s + 1000)
     out["weight_gain"] = np.float64(gain)
     if adam:

@@ -12,6 +12,7 @@ What this restates (reference = gabegrand/VQA-Counterexamples, paths relative to
 * listwise ranking loss               counterexamples.py:310,334 -> :func:`ranking_loss`
 * ``recallAtK``                       counterexamples.py:501-506 -> :func:`recall_at_k`
 * one training step (Adam)            counterexamples.py:325-339 -> :func:`train_step`
+* ``CXModelBase.vqa_forward`` + MUTAN  vqa/models/cx.py:64-104, fusion.py:78-121, noatt.py:24-29 -> :func:`mutan_vqa_forward`
 
 The arithmetic of the path is PyTorch's own operators (nn.Linear / softmax / bmm /
 pairwise_distance / CrossEntropyLoss / topk / optim.Adam); the reference pins no torch
@@ -171,6 +172,31 @@ def forward_faithful(params: Dict[str, torch.Tensor], d: Dims,
                 h = h * m / (1.0 - drop_p)
         scores.append(F.linear(h, params["out.weight"], params["out.bias"]))   # cx.py:327
     return torch.cat(scores, dim=1)                                 # cx.py:331
+
+
+# --------------------------------------------------------------------------------------
+# the frozen MUTAN producer upstream of the MLP
+# --------------------------------------------------------------------------------------
+def mutan_vqa_forward(vp: Dict[str, torch.Tensor], image_features: torch.Tensor, q_emb: torch.Tensor, R: int):
+    """CXModelBase.vqa_forward below the question encoder, op for op (vqa/models/cx.py:69-96 with
+    MutanFusion.forward, vqa/models/fusion.py:78-121, and AbstractNoAtt._classif, vqa/models/noatt.py:24-29;
+    eval mode: every dropout is the identity; options/cx/*.yaml: tanh on v and q, no other activation).
+    vp: state_dict entries of the VQA model ("fusion.linear_v.weight", ..., "linear_classif.bias").
+    -> a_orig [B,A], z_orig [B,dz], a_knns [B,K,A], z_knns [B,K,dz]."""
+    B, K1 = image_features.shape[0], image_features.shape[1]
+    v = image_features.reshape(B * K1, -1)                                             # cx.py:69-70
+    q = q_emb.view(B, 1, -1).expand(B, K1, q_emb.shape[-1]).contiguous().view(B * K1, -1)   # cx.py:83-84
+    x_v = torch.tanh(F.linear(v, vp["fusion.linear_v.weight"], vp["fusion.linear_v.bias"]))   # fusion.py:82-87
+    x_q = torch.tanh(F.linear(q, vp["fusion.linear_q.weight"], vp["fusion.linear_q.bias"]))   # fusion.py:88-93
+    x_mm = []
+    for i in range(R):                                                                 # fusion.py:96-109
+        hv = F.linear(x_v, vp["fusion.list_linear_hv.%d.weight" % i], vp["fusion.list_linear_hv.%d.bias" % i])
+        hq = F.linear(x_q, vp["fusion.list_linear_hq.%d.weight" % i], vp["fusion.list_linear_hq.%d.bias" % i])
+        x_mm.append(torch.mul(hq, hv))
+    z = torch.stack(x_mm, dim=1).sum(1)                                                # fusion.py:111-112
+    a = F.linear(z, vp["linear_classif.weight"], vp["linear_classif.bias"])            # noatt.py:28
+    a, z = a.view(B, K1, -1), z.view(B, K1, -1)                                         # cx.py:90-96
+    return a[:, 0].contiguous(), z[:, 0].contiguous(), a[:, 1:].contiguous(), z[:, 1:].contiguous()
 
 
 # --------------------------------------------------------------------------------------

@@ -199,3 +199,65 @@ def test_dp2_hip_engine_equals_dp1():
     for k, v in eng.grads.views.items():
         ref = v.cpu().numpy()
         assert np.abs(dp2[k] - ref).max() <= 1e-5 * max(np.abs(ref).max(), GRAD_FLOOR), k      # summation order only
+
+
+@pytest.mark.parametrize("name", ["g1_small_L1", "g1_small_H20_L2"])
+def test_hip_vqa_forward_vs_golden(name):
+    """ncx_vqa_forward (gather + linear_v + tanh, folded R-term fusion, classifier) against the outputs the
+    reference's own vqa_forward produced (tests/golden, G6)."""
+    from helpers import load_golden
+    from neuralcx import ops
+    g, d, spec, params, batch = load_golden(name)
+    R = int(g["vqa_R"])
+
+    class _Lin:                      # minimal stand-ins so MutanWeights can stack the golden weights
+        def __init__(self, w, b): self.weight, self.bias = w, b
+    vp = {k[4:]: torch.from_numpy(v).to(DEV) for k, v in g.items() if k.startswith("vqa/")}
+
+    class _F: pass
+    f = _F()
+    f.linear_v = _Lin(vp["fusion.linear_v.weight"], vp["fusion.linear_v.bias"])
+    f.linear_q = _Lin(vp["fusion.linear_q.weight"], vp["fusion.linear_q.bias"])
+    f.list_linear_hv = [_Lin(vp["fusion.list_linear_hv.%d.weight" % i], vp["fusion.list_linear_hv.%d.bias" % i]) for i in range(R)]
+    f.list_linear_hq = [_Lin(vp["fusion.list_linear_hq.%d.weight" % i], vp["fusion.list_linear_hq.%d.bias" % i]) for i in range(R)]
+
+    class _V: pass
+    vqa = _V()
+    vqa.fusion = f
+    vqa.linear_classif = _Lin(vp["linear_classif.weight"], vp["linear_classif.bias"])
+    vqa.opt = dict(fusion=dict(dim_hv=d.dz, dim_hq=d.dz, dim_mm=d.dz, R=R, activation_v="tanh", activation_q="tanh"), classif={})
+    mw = ops.MutanWeights(vqa)
+    feats = batch["image_features"].to(DEV)
+    B, K1, dv = feats.shape
+    idx = torch.arange(B * K1, device=DEV, dtype=torch.int32).view(B, K1)
+    a_o, z_o, a_k, z_k = ops.vqa_forward(feats.reshape(B * K1, dv).contiguous(), idx, batch["q_emb"].to(DEV), mw, want_a_orig=True)
+    for got, key in ((a_o, "a_orig"), (z_o, "z_orig"), (a_k, "a_knns"), (z_k, "z_knns")):
+        assert np.abs(got.cpu().numpy() - g[key]).max() <= 1e-4 * max(1.0, np.abs(g[key]).max()), key
+
+
+def test_hip_vqa_forward_full_dims_vs_torch_module():
+    """Full widths (dv 2048, dq 2400, dim_mm 360, R 10, 2000 answers, B=64): the HIP producer against the plain PyTorch
+    path of the same module on the GPU (hipBLASLt fp32), and NeuralModel scores through both."""
+    import vqa.models as M
+    from vqa.models.cx import NeuralModel
+    torch.manual_seed(1)
+    opt = dict(arch="MutanNoAtt", seq2vec=dict(arch="gru", emb_size=32, dropout=0.0),
+               fusion=dict(dim_v=2048, dim_q=2400, dim_hv=360, dim_hq=360, dim_mm=360, R=10, dropout_v=0.5, dropout_q=0.5,
+                           activation_v="tanh", activation_q="tanh", dropout_hv=0, dropout_hq=0), classif=dict(dropout=0.5))
+    vqa = M.factory(opt, ["w%d" % i for i in range(50)], ["a%d" % i for i in range(2000)], cuda=True, data_parallel=False)
+    spec = dict(v_emb=True, v_mult=True, v_dist=True, v_rank=True, q_emb=True, a_emb=True, z_emb=True)
+    m = NeuralModel(model_spec=spec, dim_h=256, n_layers=1, emb=None, drop_p=0.25, vqa_model=vqa, knn_size=24, trainable_vqa=False).cuda().eval()
+    B = 64
+    feats = (torch.randn(B, 25, 2048, device=DEV).abs() * 0.45)
+    wids = torch.randint(1, 51, (B, 26), device=DEV)
+    aids = torch.randint(0, 2000, (B,), device=DEV)
+    hip = m.vqa_forward(feats, wids)
+    m.use_hip_vqa = False
+    ref = m.vqa_forward(feats, wids)
+    for h, r, nm in zip(hip, ref, ("a_orig", "z_orig", "a_knns", "z_knns", "q_emb")):
+        assert h.shape == r.shape, nm
+        assert float((h - r).abs().max()) <= 2e-4 * max(1.0, float(r.abs().max())), (nm, float((h - r).abs().max()))
+    s_ref = m(feats, wids, aids)
+    m.use_hip_vqa = True
+    s_hip = m(feats, wids, aids)
+    assert float((s_hip - s_ref).detach().abs().max()) <= 1e-4

@@ -79,3 +79,13 @@ def test_train_mode_masks_change_output_consistently():
     s0, l0, _ = orc.loss_and_grads(params, d, batch, spec=spec, drop_p=0.0, keep_masks=ones)
     assert np.abs(s0.numpy() - g["scores"]).max() <= 2e-6
     assert np.abs(s1.numpy() - g["scores"]).max() > 1e-4
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if n.startswith("g1_") or n.startswith("g3_")])
+def test_mutan_vqa_forward_restatement(name):
+    """G6: the oracle's MUTAN producer against what the reference's vqa_forward handed to the MLP."""
+    g, d, spec, params, batch = load_golden(name)
+    vp = {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("vqa/")}
+    a_o, z_o, a_k, z_k = orc.mutan_vqa_forward(vp, batch["image_features"], batch["q_emb"], int(g["vqa_R"]))
+    for got, key in ((a_o, "a_orig"), (z_o, "z_orig"), (a_k, "a_knns"), (z_k, "z_knns")):
+        assert np.abs(got.numpy() - g[key]).max() <= 2e-6 * max(1.0, np.abs(g[key]).max()), key

@@ -939,6 +939,107 @@ int ncx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
     return NCX_OK;
 }
 
+// ---- fused MUTAN producer ---------------------------------------------------------------------------
+struct VqaLayout { size_t xq, hq, xv, slab, slab_bytes, total; };
+static VqaLayout vqa_layout(const ncx_dims& d, const ncx_mutan_params& m, GemmPlan* plans /*[5]*/) {
+    VqaLayout w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const long long Mv = (long long)d.B * (d.K + 1), RZ = (long long)m.R * d.dz;
+    w.xq = take((size_t)d.B * m.dhq * 4);
+    w.hq = take((size_t)d.B * RZ * 4);
+    w.xv = take((size_t)Mv * m.dhv * 4);
+    // 0: xq = act(q Wq^T)  1: hq = xq Whq^T  2: xv = act(gather(v) Wv^T)  3: z (fold, never split)  4: a = z Wc^T
+    const long long shp[5][3] = {{d.B, m.dhq, ks(d.dq)}, {d.B, RZ, ks(m.dhq)}, {Mv, m.dhv, ks(d.dv)}, {Mv, d.dz, 0}, {(long long)d.B * d.K, d.A, ks(d.dz)}};
+    long long slab = 0;
+    for (int i = 0; i < 5; ++i) {
+        plans[i] = plan_gemm(FORM_NT, shp[i][0], shp[i][1], shp[i][2], true);
+        if (i == 3) { plans[i].cfg = CFG_64x64; plans[i].split = 1; }
+        int bm, bn; cfg_tile(plans[i].cfg, bm, bn);
+        const long long e = plans[i].split > 1 ? cdiv(shp[i][0], bm) * cdiv(shp[i][1], bn) * plans[i].split * bm * bn : 0;
+        if (e > slab) slab = e;
+    }
+    w.slab_bytes = (size_t)slab * 4;
+    w.slab = take(w.slab_bytes);
+    w.total = off;
+    return w;
+}
+static int check_mutan(const ncx_dims* d, const ncx_mutan_params* m) {
+    if (!d || !m) return NCX_E_NULL;
+    if (d->B < 1 || d->K < 1 || d->dv < 4 || d->dq < 4 || d->dz < 4 || d->A < 4 || d->n_img < 1) return NCX_E_DIMS;
+    if (m->dhv < 4 || m->dhq < 4 || m->R < 1 || m->R > NCX_MAX_SEG) return NCX_E_DIMS;
+    if ((m->act_v != 0 && m->act_v != 2) || (m->act_q != 0 && m->act_q != 2)) return NCX_E_FLAGS;
+    if (!m->wv || !m->bv || !m->wq || !m->bq || !m->whv || !m->bhv || !m->whq || !m->bhq || !m->wc || !m->bc) return NCX_E_NULL;
+    return NCX_OK;
+}
+
+size_t ncx_vqa_workspace_bytes(const ncx_dims* d, const ncx_mutan_params* m) {
+    if (check_mutan(d, m) != NCX_OK) return 0;
+    GemmPlan plans[5];
+    return vqa_layout(*d, *m, plans).total;
+}
+
+int ncx_vqa_forward(const ncx_dims* dp, const float* feats, const int32_t* img_idx, const float* q_emb,
+                    const ncx_mutan_params* mp, void* workspace, size_t workspace_bytes,
+                    float* z_orig, float* z_knns, float* a_knns, float* a_orig, void* stream_) {
+    int rc = check_mutan(dp, mp);
+    if (rc != NCX_OK) return rc;
+    if (!feats || !img_idx || !q_emb || !workspace || !z_orig || !z_knns || !a_knns) return NCX_E_NULL;
+    const ncx_dims& d = *dp; const ncx_mutan_params& m = *mp;
+    GemmPlan plans[5];
+    const VqaLayout w = vqa_layout(d, m, plans);
+    if (workspace_bytes < w.total || ((uintptr_t)workspace & 255)) return NCX_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    float* xq = (float*)(ws + w.xq); float* hq = (float*)(ws + w.hq); float* xv = (float*)(ws + w.xv);
+    float* slab = (float*)(ws + w.slab);
+    const int Mv = d.B * (d.K + 1), RZ = m.R * d.dz;
+    {   // x_q = act_q(q . Wq^T + bq)                                            fusion.py:88-93
+        GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = d.B;
+        a.a[0] = x_plain(q_emb, d.dq, d.B, d.dq); a.b[0] = x_plain(m.wq, d.dq, m.dhq, d.dq); a.klen[0] = d.dq;
+        a.out[0] = xq; a.ldo[0] = m.dhq; a.n_cols[0] = m.dhq; a.epi.relu = m.act_q;
+        rc = run_gemm_impl(a, FORM_NT, plans[0], slab, w.slab_bytes, m.bq, s); if (rc) return rc;
+    }
+    {   // hq[b][r*dz + j] = x_q . Whq_r^T + bhq_r   (all R at once)               fusion.py:103-107
+        GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = d.B;
+        a.a[0] = x_plain(xq, m.dhq, d.B, m.dhq); a.b[0] = x_plain(m.whq, m.dhq, RZ, m.dhq); a.klen[0] = m.dhq;
+        a.out[0] = hq; a.ldo[0] = RZ; a.n_cols[0] = RZ;
+        rc = run_gemm_impl(a, FORM_NT, plans[1], slab, w.slab_bytes, m.bhq, s); if (rc) return rc;
+    }
+    {   // x_v = act_v(gather(feats, img_idx) . Wv^T + bv) for the B*(K+1) images      fusion.py:82-87 (+ the host gather)
+        GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = Mv;
+        a.a[0] = x_gather(feats, d.dv, img_idx, Mv, d.dv); a.b[0] = x_plain(m.wv, d.dv, m.dhv, d.dv); a.klen[0] = d.dv;
+        a.out[0] = xv; a.ldo[0] = m.dhv; a.n_cols[0] = m.dhv; a.epi.relu = m.act_v;
+        rc = run_gemm_impl(a, FORM_NT, plans[2], slab, w.slab_bytes, m.bv, s); if (rc) return rc;
+    }
+    {   // z = sum_r (x_v . Whv_r^T + bhv_r) * hq_r[question]  -> z_orig / z_knns     fusion.py:96-115
+        GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = m.R; a.M = Mv;
+        for (int r = 0; r < m.R; ++r) {
+            a.a[r] = x_plain(xv, m.dhv, Mv, m.dhv);
+            a.b[r] = x_plain(m.whv + (long long)r * d.dz * m.dhv, m.dhv, d.dz, m.dhv);
+            a.klen[r] = m.dhv;
+        }
+        a.out[0] = z_knns; a.ldo[0] = d.dz; a.n_cols[0] = d.dz; a.split[0] = 1;
+        a.epi.fold_mul = hq; a.epi.ld_fold = RZ; a.epi.fold_div = d.K + 1; a.epi.fold_bias = m.bhv;
+        a.epi.rowsplit_g = d.K + 1; a.epi.out0 = z_orig; a.epi.ldo0 = d.dz;
+        rc = run_gemm_nt_fold(a, s); if (rc) return rc;
+    }
+    {   // a_knns = z_knns . Wc^T + bc                                               noatt.py:24-29 (dropout off in eval)
+        GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = d.B * d.K;
+        a.a[0] = x_plain(z_knns, d.dz, d.B * d.K, d.dz); a.b[0] = x_plain(m.wc, d.dz, d.A, d.dz); a.klen[0] = d.dz;
+        a.out[0] = a_knns; a.ldo[0] = d.A; a.n_cols[0] = d.A;
+        rc = run_gemm_impl(a, FORM_NT, plans[4], slab, w.slab_bytes, m.bc, s); if (rc) return rc;
+    }
+    if (a_orig) {
+        GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = d.B;
+        a.a[0] = x_plain(z_orig, d.dz, d.B, d.dz); a.b[0] = x_plain(m.wc, d.dz, d.A, d.dz); a.klen[0] = d.dz;
+        a.out[0] = a_orig; a.ldo[0] = d.A; a.n_cols[0] = d.A; a.split[0] = 1;
+        GemmPlan pl; pl.cfg = CFG_64x64; pl.split = 1;
+        rc = run_gemm_impl(a, FORM_NT, pl, slab, w.slab_bytes, m.bc, s); if (rc) return rc;
+    }
+    return NCX_OK;
+}
+
 // ---- diagnostics ---------------------------------------------------------------------------------------
 int ncx_profile_begin(uint32_t gemm_mask, int32_t max_launches) {
     if (g_prof.on || gemm_mask == 0 || (gemm_mask >> U_COUNT) != 0 || max_launches < 1 || max_launches > 65536) return NCX_E_DIMS;

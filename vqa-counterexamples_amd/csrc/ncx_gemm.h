@@ -72,12 +72,17 @@ enum GemmMode : int { MODE_CHAIN = 0, MODE_GROUP = 1 };
 struct EpiArgs {
     const float* rowadd; long long ld_rowadd; int rowdiv;
     const float* bias;
-    int relu;
+    int relu;                    // activation: 0 none, 1 relu, 2 tanh
     int dropout;                 // 0 none, 1 counter-based generator, 2 explicit keep mask
     float drop_p, drop_scale;
     unsigned seed_lo, seed_hi, layer;
     const float* keep_mask; long long ld_mask;
     const float* gate; long long ld_gate; float gate_scale;   // v *= gate[r][n] > 0 ? gate_scale : 0
+    // FOLD kernels only (MUTAN fusion, fusion.py:96-115): after every chained pair s,
+    //   zacc += (acc + fold_bias[s*N + n]) * fold_mul[(r / fold_div)*ld_fold + s*N + n];  acc = 0;   output = zacc
+    const float* fold_mul; const float* fold_bias; long long ld_fold; int fold_div;
+    // split output rows: row r = g*b + j goes to out0[b] when j == 0, else to out[(g-1)*b + j-1]   (0: off)
+    int rowsplit_g; float* out0; long long ldo0;
 };
 
 struct GemmArgs {
@@ -369,7 +374,8 @@ struct GemmCfg {
 __device__ __forceinline__ float apply_epilogue(const EpiArgs& e, float v, int r, int n, int ncols_total) {
     if (e.rowadd) v += e.rowadd[(long long)(r / e.rowdiv) * e.ld_rowadd + n];
     if (e.bias) v += e.bias[n];
-    if (e.relu) v = v > 0.f ? v : 0.f;
+    if (e.relu == 1) v = v > 0.f ? v : 0.f;
+    else if (e.relu == 2) v = tanhf(v);                      // activation_v / activation_q = tanh (fusion.py:84-93)
     if (e.dropout == 1) {
         v = dropout_keep(e.seed_lo, e.seed_hi, e.layer, (unsigned long long)r * (unsigned)ncols_total + (unsigned)n, e.drop_p)
                 ? v * e.drop_scale : 0.f;
@@ -382,7 +388,7 @@ __device__ __forceinline__ float apply_epilogue(const EpiArgs& e, float v, int r
 
 // Big tiles get the whole 512-entry register file (one workgroup per CU): at 2 waves per SIMD the 128x128 and
 // 96x128 instantiations spill 90-260 VGPRs.
-template <int BM, int BN, bool A_COLK, bool B_COLK>
+template <int BM, int BN, bool A_COLK, bool B_COLK, bool FOLD = false>
 __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_kernel(const GemmArgs args) {
     typedef GemmCfg<BM, BN, A_COLK, B_COLK> Cfg;
     constexpr int BK = Cfg::BK, PA = Cfg::PA, PB = Cfg::PB, WM = Cfg::WM, WN = Cfg::WN;
@@ -397,6 +403,13 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
 
     const int M = args.M;
     f32x4 acc[WM][WN];
+    f32x4 zacc[FOLD ? WM : 1][FOLD ? WN : 1];
+    if (FOLD) {
+#pragma unroll
+        for (int i = 0; i < (FOLD ? WM : 1); ++i)
+#pragma unroll
+            for (int j = 0; j < (FOLD ? WN : 1); ++j) zacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   // Optional persistent loop (NCX_PERSISTENT=1; default: one workgroup per item): the grid holds at most one workgroup per resident slot (a multiple of 8, so item % 8 -- the XCD
   // affinity WgMap is built on -- is the same for every item of a workgroup); a slot then never idles between the
   // exit of one short workgroup and the dispatch of the next.
@@ -724,6 +737,24 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
                 lb.prefetch_rows(args.b[nseg], nkpos + BK, tid);
             }
             compute(buf);
+            if (FOLD && (!has_next || nseg != seg)) {                // pair `seg` is complete: fold it into zacc
+#pragma unroll
+                for (int i = 0; i < (FOLD ? WM : 1); ++i)
+#pragma unroll
+                    for (int j = 0; j < (FOLD ? WN : 1); ++j) {
+                        const int n = n0 + tcol(j, li);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int r = m0 + trow(i, lk * 4 + q);
+                            if (r < M && n < N) {
+                                const long long c = (long long)seg * N + n;
+                                zacc[i][j][q] += (acc[i][j][q] + args.epi.fold_bias[c]) *
+                                                 args.epi.fold_mul[(long long)(r / args.epi.fold_div) * args.epi.ld_fold + c];
+                            }
+                            acc[i][j][q] = 0.f;
+                        }
+                    }
+            }
             if (has_next) {
                 la.store(lds_a + (buf ^ 1) * Cfg::A_ELEMS, nkpos, tid);
                 lb.store(lds_b + (buf ^ 1) * Cfg::B_ELEMS, nkpos, tid);
@@ -757,7 +788,17 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = m0 + trow(i, lk * 4 + q);
-                if (r < M && n < N) out[(long long)r * ldo + n] = apply_epilogue(args.epi, acc[i][j][q], r, n, N);
+                if (r < M && n < N) {
+                    const float v = apply_epilogue(args.epi, FOLD ? zacc[FOLD ? i : 0][FOLD ? j : 0][q] : acc[i][j][q], r, n, N);
+                    const int g = args.epi.rowsplit_g;
+                    if (g > 0) {
+                        const int b = r / g, jj = r - b * g;
+                        if (jj == 0) args.epi.out0[(long long)b * args.epi.ldo0 + n] = v;
+                        else out[((long long)b * (g - 1) + jj - 1) * ldo + n] = v;
+                    } else {
+                        out[(long long)r * ldo + n] = v;
+                    }
+                }
             }
         }
     }
@@ -772,7 +813,7 @@ struct FixupArgs {
     int tile0[NCX_MAX_SEG + 1]; int wg0[NCX_MAX_SEG + 1];
     const float* bias;
     const float* slab;
-    int mode, nseg, M, pad_;
+    int mode, nseg, M, act;      // act: 0 none, 1 relu, 2 tanh (applied after the bias)
 };
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void split_fixup_kernel(const FixupArgs a) {
@@ -800,7 +841,11 @@ __global__ __launch_bounds__(256) void split_fixup_kernel(const FixupArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int gc = n0 + c + j;
-            if (gc < N) out[(long long)gr * ldo + gc] = acc4[j] + (a.bias ? a.bias[gc] : 0.f);
+            if (gc < N) {
+                float v = acc4[j] + (a.bias ? a.bias[gc] : 0.f);
+                if (a.act == 1) v = v > 0.f ? v : 0.f; else if (a.act == 2) v = tanhf(v);
+                out[(long long)gr * ldo + gc] = v;
+            }
         }
     }
 }
@@ -823,20 +868,20 @@ static inline long long gemm_layout(GemmArgs& args, int BM, int BN, bool* any_sp
 }
 
 // Resident workgroups per CU of an instantiation (registers / LDS), for the planner; 2 when no device is present.
-template <int BM, int BN, bool A_COLK, bool B_COLK>
+template <int BM, int BN, bool A_COLK, bool B_COLK, bool FOLD = false>
 static inline int seg_gemm_occupancy() {
     typedef GemmCfg<BM, BN, A_COLK, B_COLK> Cfg;
     int n = 0;
-    (void)hipFuncSetAttribute((const void*)seg_gemm_kernel<BM, BN, A_COLK, B_COLK>,
+    (void)hipFuncSetAttribute((const void*)seg_gemm_kernel<BM, BN, A_COLK, B_COLK, FOLD>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, seg_gemm_kernel<BM, BN, A_COLK, B_COLK>, 256, Cfg::LDS_BYTES) != hipSuccess || n < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, seg_gemm_kernel<BM, BN, A_COLK, B_COLK, FOLD>, 256, Cfg::LDS_BYTES) != hipSuccess || n < 1) {
         (void)hipGetLastError();
         n = 2;
     }
     return n;
 }
 
-template <int BM, int BN, bool A_COLK, bool B_COLK>
+template <int BM, int BN, bool A_COLK, bool B_COLK, bool FOLD = false>
 static inline hipError_t launch_seg_gemm(GemmArgs& args, hipStream_t stream) {
     typedef GemmCfg<BM, BN, A_COLK, B_COLK> Cfg;
     bool any_split = false;
@@ -844,7 +889,7 @@ static inline hipError_t launch_seg_gemm(GemmArgs& args, hipStream_t stream) {
     if (wgs == 0) return hipSuccess;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)seg_gemm_kernel<BM, BN, A_COLK, B_COLK>,
+        hipError_t e = hipFuncSetAttribute((const void*)seg_gemm_kernel<BM, BN, A_COLK, B_COLK, FOLD>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -856,7 +901,7 @@ static inline hipError_t launch_seg_gemm(GemmArgs& args, hipStream_t stream) {
         if (!slots) {
             int dev = 0, cus = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) { (void)hipGetLastError(); cus = 256; }
-            slots = seg_gemm_occupancy<BM, BN, A_COLK, B_COLK>() * cus;
+            slots = seg_gemm_occupancy<BM, BN, A_COLK, B_COLK, FOLD>() * cus;
             slots -= slots % 8;
         }
         // Measured (grouped dW1, 5856 items on 768 slots): 0.526 ms persistent vs 0.474 ms with one workgroup per
@@ -864,14 +909,14 @@ static inline hipError_t launch_seg_gemm(GemmArgs& args, hipStream_t stream) {
         const char* pe = getenv("NCX_PERSISTENT");
         if (pe && atoi(pe) && wgs > 2 * slots) grid = slots;
     }
-    hipLaunchKernelGGL((seg_gemm_kernel<BM, BN, A_COLK, B_COLK>), dim3((unsigned)grid), dim3(256), Cfg::LDS_BYTES, stream, args);
+    hipLaunchKernelGGL((seg_gemm_kernel<BM, BN, A_COLK, B_COLK, FOLD>), dim3((unsigned)grid), dim3(256), Cfg::LDS_BYTES, stream, args);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !any_split) return e;
     FixupArgs f{};
     const int np = args.mode == MODE_GROUP ? args.nseg : 1;
     for (int i = 0; i < np; ++i) { f.out[i] = args.out[i]; f.ldo[i] = args.ldo[i]; f.n_cols[i] = args.n_cols[i]; f.split[i] = args.split[i]; }
     for (int i = 0; i <= np; ++i) { f.tile0[i] = args.tile0[i]; f.wg0[i] = args.wg0[i]; }
-    f.bias = args.epi.bias; f.slab = args.slab; f.mode = args.mode; f.nseg = args.nseg; f.M = args.M;
+    f.bias = args.epi.bias; f.slab = args.slab; f.mode = args.mode; f.nseg = args.nseg; f.M = args.M; f.act = args.epi.relu;
     hipLaunchKernelGGL((split_fixup_kernel<BM, BN>), dim3(args.tile0[np], BM * BN / 1024), dim3(256), 0, stream, f);
     return hipGetLastError();
 }

@@ -15,6 +15,9 @@ int run_gemm_nt(GemmArgs& a, int cfg, hipStream_t s) {
     default:          return (int)launch_seg_gemm<64, 64, true, true>(a, s);
     }
 }
+// chained pairs folded into a second accumulator (MUTAN fusion); 64x64 tiles: M = B*(K+1) rows x N = dim_mm
+int run_gemm_nt_fold(GemmArgs& a, hipStream_t s) { return (int)launch_seg_gemm<64, 64, true, true, true>(a, s); }
+
 int occupancy_nt(int cfg) {
     static int occ[4] = {0, 0, 0, 0};
     if (!occ[cfg & 3]) {

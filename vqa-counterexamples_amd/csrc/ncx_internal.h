@@ -9,6 +9,7 @@ enum TileCfg : int { CFG_64x64 = 0, CFG_128x128 = 1, CFG_96x128 = 2, CFG_96x64 =
 enum GemmForm : int { FORM_NT = 0, FORM_TN = 1, FORM_NN = 2 };
 
 int run_gemm_nt(GemmArgs& a, int cfg, hipStream_t s);
+int run_gemm_nt_fold(GemmArgs& a, hipStream_t s);
 int run_gemm_tn(GemmArgs& a, int cfg, hipStream_t s);
 int run_gemm_nn(GemmArgs& a, int cfg, hipStream_t s);
 int occupancy_nt(int cfg);

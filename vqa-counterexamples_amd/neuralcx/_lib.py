@@ -14,7 +14,8 @@ NCX_F_V_MULT, NCX_F_V_DIST, NCX_F_V_RANK, NCX_F_A_EMB = 1, 2, 4, 8
 NCX_F_ALL = 15
 
 EXPORTS = ("ncx_input_size", "ncx_workspace_bytes", "ncx_forward", "ncx_loss_rank", "ncx_backward", "ncx_backward_phase",
-           "ncx_adam_step", "ncx_version", "ncx_profile_begin", "ncx_profile_end", "ncx_plan_query")
+           "ncx_adam_step", "ncx_version", "ncx_profile_begin", "ncx_profile_end", "ncx_plan_query",
+           "ncx_vqa_workspace_bytes", "ncx_vqa_forward")
 
 
 class NcxDims(C.Structure):
@@ -39,6 +40,11 @@ class NcxParams(C.Structure):
 
 class NcxGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _PNAMES]
+
+
+class NcxMutanParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("wv", "bv", "wq", "bq", "whv", "bhv", "whq", "bhq", "wc", "bc")] + \
+               [(n, C.c_int32) for n in ("dhv", "dhq", "R", "act_v", "act_q")]
 
 
 class NcxError(RuntimeError):
@@ -80,6 +86,11 @@ def lib():
     L.ncx_adam_step.restype = C.c_int
     L.ncx_adam_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float,
                                 C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float, C.c_void_p]
+    L.ncx_vqa_workspace_bytes.restype = C.c_size_t
+    L.ncx_vqa_workspace_bytes.argtypes = [C.POINTER(NcxDims), C.POINTER(NcxMutanParams)]
+    L.ncx_vqa_forward.restype = C.c_int
+    L.ncx_vqa_forward.argtypes = [C.POINTER(NcxDims), C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(NcxMutanParams), C.c_void_p,
+                                  C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ncx_profile_begin.restype = C.c_int
     L.ncx_profile_begin.argtypes = [C.c_uint32, C.c_int32]
     L.ncx_profile_end.restype = C.c_int

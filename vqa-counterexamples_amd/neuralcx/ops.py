@@ -15,7 +15,7 @@ import torch
 
 from . import _lib
 from ._lib import (NCX_F_A_EMB, NCX_F_ALL, NCX_F_V_DIST, NCX_F_V_MULT, NCX_F_V_RANK, NcxDims, NcxGrads,
-                   NcxInputs, NcxParams)
+                   NcxInputs, NcxMutanParams, NcxParams)
 
 PARAM_FIELDS = ("answer_embedding", "w1", "b1", "w2", "b2", "w3", "b3", "w_out", "b_out")
 # state_dict names of the reference (vqa/models/cx.py:240-257) -> C ABI field
@@ -184,6 +184,62 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr=1e-4, betas=(0.9, 0.999
                                         _ptr(exp_avg, torch.float32, "exp_avg"), _ptr(exp_avg_sq, torch.float32, "exp_avg_sq"),
                                         n, lr, betas[0], betas[1], eps, int(step), float(grad_scale), _stream()),
                "ncx_adam_step")
+
+
+class MutanWeights:
+    """Frozen MutanNoAtt parameters in the layout ncx_vqa_forward wants: the R rank-1 projections stacked
+    (fusion.list_linear_hv.{i} -> [R*dim_mm, dim_hv]).  Built once per model; re-stack after loading a checkpoint."""
+
+    def __init__(self, vqa_model):
+        f, opt = vqa_model.fusion, vqa_model.opt["fusion"]
+        for k in ("activation_hv", "activation_hq", "activation_mm"):
+            if k in opt:
+                raise _lib.NcxError("ncx_vqa_forward supports the options/cx/*.yaml MUTAN (no %s)" % k)
+        if "activation" in vqa_model.opt.get("classif", {}):
+            raise _lib.NcxError("ncx_vqa_forward: classif.activation is not supported")
+        act = {None: 0, "tanh": 2}
+        if opt.get("activation_v") not in act or opt.get("activation_q") not in act:
+            raise _lib.NcxError("ncx_vqa_forward supports activation_v/q in {none, tanh}")
+        c = lambda t: t.detach().float().contiguous()
+        self.t = dict(wv=c(f.linear_v.weight), bv=c(f.linear_v.bias), wq=c(f.linear_q.weight), bq=c(f.linear_q.bias),
+                      whv=c(torch.cat([l.weight for l in f.list_linear_hv])), bhv=c(torch.cat([l.bias for l in f.list_linear_hv])),
+                      whq=c(torch.cat([l.weight for l in f.list_linear_hq])), bhq=c(torch.cat([l.bias for l in f.list_linear_hq])),
+                      wc=c(vqa_model.linear_classif.weight), bc=c(vqa_model.linear_classif.bias))
+        self.dhv, self.dhq, self.R, self.dz = opt["dim_hv"], opt["dim_hq"], opt["R"], opt["dim_mm"]
+        self.A = self.t["wc"].shape[0]
+        self.act_v, self.act_q = act[opt.get("activation_v")], act[opt.get("activation_q")]
+
+    def c_struct(self):
+        m = NcxMutanParams()
+        for k, v in self.t.items():
+            setattr(m, k, _ptr(v, torch.float32, k))
+        m.dhv, m.dhq, m.R, m.act_v, m.act_q = self.dhv, self.dhq, self.R, self.act_v, self.act_q
+        return m
+
+
+def vqa_forward(feats: torch.Tensor, img_idx: torch.Tensor, q_emb: torch.Tensor, mw: MutanWeights, want_a_orig=False, ws=None):
+    """HIP replacement of CXModelBase.vqa_forward below the question encoder (cx.py:64-104).
+    -> (a_orig or None, z_orig [B,dz], a_knns [B,K,A], z_knns [B,K,dz])."""
+    B, K1 = img_idx.shape
+    d = NcxDims()
+    d.B, d.K, d.dv, d.dq, d.dz, d.da, d.A, d.H, d.L = B, K1 - 1, feats.shape[1], q_emb.shape[1], mw.dz, 4, mw.A, 4, 1
+    d.n_img = feats.shape[0]
+    m = mw.c_struct()
+    need = _lib.lib().ncx_vqa_workspace_bytes(C.byref(d), C.byref(m))
+    if need == 0:
+        raise _lib.NcxError("ncx_vqa_workspace_bytes: invalid dims")
+    if ws is None or ws.numel() < need + 256:
+        ws = torch.empty(need + 256, dtype=torch.uint8, device=feats.device)
+    dev = feats.device
+    z_o = torch.empty(B, mw.dz, device=dev); z_k = torch.empty(B, K1 - 1, mw.dz, device=dev)
+    a_k = torch.empty(B, K1 - 1, mw.A, device=dev)
+    a_o = torch.empty(B, mw.A, device=dev) if want_a_orig else None
+    p, n = _ws_ptr(ws)
+    _lib.check(_lib.lib().ncx_vqa_forward(C.byref(d), _ptr(feats, torch.float32, "feats"), _ptr(img_idx, torch.int32, "img_idx"),
+                                          _ptr(q_emb, torch.float32, "q_emb"), C.byref(m), p, n, C.c_void_p(z_o.data_ptr()),
+                                          C.c_void_p(z_k.data_ptr()), C.c_void_p(a_k.data_ptr()),
+                                          C.c_void_p(a_o.data_ptr()) if a_o is not None else None, _stream()), "ncx_vqa_forward")
+    return a_o, z_o, a_k, z_k
 
 
 class NeuralCXFunction(torch.autograd.Function):

@@ -55,22 +55,42 @@ class CXModelBase(nn.Module):
             self.vqa_model.eval()
         self.knn_size = knn_size
 
+    def _hip_vqa_ok(self, image_features):
+        from .noatt import MutanNoAtt
+        return (isinstance(self.vqa_model, MutanNoAtt) and image_features.is_cuda and not self.trainable_vqa
+                and getattr(self, "use_hip_vqa", True))
+
     @torch.no_grad()
     def vqa_forward(self, image_features, question_wids):
         """Frozen VQA model on the original + K candidate images -> a_orig, z_orig, a_knns, z_knns, q_emb
-        (same outputs as cx.py:64-104).  The question branch of the fusion is computed once per question
-        instead of K+1 times (the reference duplicates q first, cx.py:83-87)."""
+        (same outputs as cx.py:64-104).  For MutanNoAtt on the GPU everything below the question encoder runs in
+        the HIP library (ncx_vqa_forward: gather + linear_v + tanh, R-term fusion folded in one chained GEMM,
+        classifier); otherwise plain PyTorch.  Either way the question branch is computed once per question
+        (the reference duplicates q K+1 times first, cx.py:83-87)."""
         assert image_features.size(1) == self.knn_size + 1
         B, K1 = image_features.size(0), self.knn_size + 1
         vqa = self.vqa_model
         vqa.eval()
-        v = image_features.reshape(B * K1, -1)
         q_emb = vqa.seq2vec(question_wids)
+        if self._hip_vqa_ok(image_features):
+            mw = self.__dict__.get("_mutan_weights")
+            if mw is None or mw.t["wv"].device != image_features.device:
+                mw = ops.MutanWeights(vqa)
+                self.__dict__["_mutan_weights"] = mw
+            feats = image_features.reshape(B * K1, -1).float().contiguous()
+            idx = torch.arange(B * K1, device=feats.device, dtype=torch.int32).view(B, K1)
+            a_o, z_o, a_k, z_k = ops.vqa_forward(feats, idx, q_emb.float().contiguous(), mw, want_a_orig=True)
+            return a_o, z_o, a_k, z_k, q_emb
+        v = image_features.reshape(B * K1, -1)
         q_dup = q_emb.view(B, 1, -1).expand(B, K1, q_emb.size(-1)).reshape(B * K1, -1)
         z = vqa._fusion(v, q_dup)
         a = vqa._classif(z)
         a, z = a.view(B, K1, -1), z.view(B, K1, -1)
         return (a[:, 0].contiguous(), z[:, 0].contiguous(), a[:, 1:].contiguous(), z[:, 1:].contiguous(), q_emb)
+
+    def refresh_vqa_weights(self):
+        """Call after loading a VQA checkpoint: the stacked MUTAN weights of the HIP path are cached."""
+        self.__dict__.pop("_mutan_weights", None)
 
     def forward(self, image_features, question_wids, answer_aids):
         raise NotImplementedError
