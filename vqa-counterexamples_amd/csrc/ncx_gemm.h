@@ -738,22 +738,28 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
             }
             compute(buf);
             if (FOLD && (!has_next || nseg != seg)) {                // pair `seg` is complete: fold it into zacc
+                // operands fetched with clamped indices and no branches (guarded loads serialise at L2 latency)
 #pragma unroll
-                for (int i = 0; i < (FOLD ? WM : 1); ++i)
+                for (int i = 0; i < (FOLD ? WM : 1); ++i) {
+                    float fb[WN], fm[WN][4];
 #pragma unroll
                     for (int j = 0; j < (FOLD ? WN : 1); ++j) {
-                        const int n = n0 + tcol(j, li);
+                        const long long c = (long long)seg * N + min(n0 + tcol(j, li), N - 1);
+                        fb[j] = args.epi.fold_bias[c];
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const int r = m0 + trow(i, lk * 4 + q);
-                            if (r < M && n < N) {
-                                const long long c = (long long)seg * N + n;
-                                zacc[i][j][q] += (acc[i][j][q] + args.epi.fold_bias[c]) *
-                                                 args.epi.fold_mul[(long long)(r / args.epi.fold_div) * args.epi.ld_fold + c];
-                            }
-                            acc[i][j][q] = 0.f;
+                            const int r = min(m0 + trow(i, lk * 4 + q), M - 1);
+                            fm[j][q] = args.epi.fold_mul[(long long)(r / args.epi.fold_div) * args.epi.ld_fold + c];
                         }
                     }
+#pragma unroll
+                    for (int j = 0; j < (FOLD ? WN : 1); ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            zacc[FOLD ? i : 0][FOLD ? j : 0][q] += (acc[i][j][q] + fb[j]) * fm[j][q];
+                            acc[i][j][q] = 0.f;
+                        }
+                }
             }
             if (has_next) {
                 la.store(lds_a + (buf ^ 1) * Cfg::A_ELEMS, nkpos, tid);
@@ -780,20 +786,46 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
     }
     float* out = args.out[args.mode == MODE_GROUP ? prob : 0];
     const long long ldo = args.ldo[args.mode == MODE_GROUP ? prob : 0];
+    const EpiArgs& e = args.epi;
+    // Per row-block: every operand of the epilogue (row add, bias, dropout mask, gate) is fetched first, with
+    // clamped indices and without per-element branches, then the block is finished and stored.  (A guard around
+    // each load put it in its own basic block: 48-64 serialised L2 round trips per workgroup.)
+    float bias_v[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) bias_v[j] = e.bias ? e.bias[min(n0 + tcol(j, li), N - 1)] : 0.f;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
+        float addv[WN][4], gatev[WN][4], maskv[WN][4];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int nc = min(n0 + tcol(j, li), N - 1);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rc = min(m0 + trow(i, lk * 4 + q), M - 1);
+                addv[j][q] = e.rowadd ? e.rowadd[(long long)(rc / e.rowdiv) * e.ld_rowadd + nc] : 0.f;
+                gatev[j][q] = e.gate ? e.gate[(long long)rc * e.ld_gate + nc] : 1.f;
+                maskv[j][q] = e.dropout == 2 ? e.keep_mask[(long long)rc * e.ld_mask + nc] : 1.f;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             const int n = n0 + tcol(j, li);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = m0 + trow(i, lk * 4 + q);
+                float v = (FOLD ? zacc[FOLD ? i : 0][FOLD ? j : 0][q] : acc[i][j][q]) + addv[j][q] + bias_v[j];
+                if (e.relu == 1) v = v > 0.f ? v : 0.f;
+                else if (e.relu == 2) v = tanhf(v);
+                if (e.dropout == 1)
+                    v = dropout_keep(e.seed_lo, e.seed_hi, e.layer, (unsigned long long)r * (unsigned)N + (unsigned)n, e.drop_p) ? v * e.drop_scale : 0.f;
+                else if (e.dropout == 2)
+                    v = maskv[j][q] != 0.f ? v * e.drop_scale : 0.f;
+                if (e.gate) v = gatev[j][q] > 0.f ? v * e.gate_scale : 0.f;
                 if (r < M && n < N) {
-                    const float v = apply_epilogue(args.epi, FOLD ? zacc[FOLD ? i : 0][FOLD ? j : 0][q] : acc[i][j][q], r, n, N);
-                    const int g = args.epi.rowsplit_g;
+                    const int g = e.rowsplit_g;
                     if (g > 0) {
                         const int b = r / g, jj = r - b * g;
-                        if (jj == 0) args.epi.out0[(long long)b * args.epi.ldo0 + n] = v;
+                        if (jj == 0) e.out0[(long long)b * e.ldo0 + n] = v;
                         else out[((long long)b * (g - 1) + jj - 1) * ldo + n] = v;
                     } else {
                         out[(long long)r * ldo + n] = v;
