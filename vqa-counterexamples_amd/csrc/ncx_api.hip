@@ -418,6 +418,11 @@ static GemmPlan plan_from_tiles(int form, long long tiles_big, long long tiles_s
 GemmPlan plan_gemm(int form, long long M, long long N, long long ksteps, bool allow_96) {
     // Epilogue GEMMs (forward layers) never split; both big NT tiles run one workgroup per CU, so pick the one
     // whose tile count fills whole rounds of CUs better (H=512: 384 tiles of 128x128 = 1.5 rounds, 512 of 96x128 = 2).
+    // Short reductions (<= 32 k-steps, e.g. the 360-wide MUTAN / classifier products): the per-workgroup prologue and
+    // epilogue of the big tiles dominate; measured at M=12288, N=2000, K=360: 645 / 335 / 245 us for 128x128 / 96x128 / 64x64.
+    if (form == FORM_NT && allow_96 && ksteps <= 32 && M * N >= 64 * 64 * 512) {
+        GemmPlan p; p.cfg = CFG_64x64; p.split = 1; return p;
+    }
     if (form == FORM_NT && allow_96 && M >= 96 && N >= 128) {
         const double cus = (double)num_cus();
         const double t128 = (double)(cdiv(M, 128) * cdiv(N, 128)), t96 = (double)(cdiv(M, 96) * cdiv(N, 128));
@@ -954,6 +959,11 @@ static VqaLayout vqa_layout(const ncx_dims& d, const ncx_mutan_params& m, GemmPl
     long long slab = 0;
     for (int i = 0; i < 5; ++i) {
         plans[i] = plan_gemm(FORM_NT, shp[i][0], shp[i][1], shp[i][2], true);
+        {   // experiment hook
+            char name[32]; snprintf(name, sizeof name, "NCX_VQA_CFG_%d", i);
+            const char* c = getenv(name);
+            if (c) { plans[i].cfg = atoi(c); plans[i].split = 1; }
+        }
         if (i == 3) { plans[i].cfg = CFG_64x64; plans[i].split = 1; }
         int bm, bn; cfg_tile(plans[i].cfg, bm, bn);
         const long long e = plans[i].split > 1 ? cdiv(shp[i][0], bm) * cdiv(shp[i][1], bn) * plans[i].split * bm * bn : 0;

@@ -290,7 +290,7 @@ struct OpLoader {
             if (KIND == X_GATHER_MUL) nidx1 = d.idx2[(long long)(min(r + idx_ahead, rows - 1)) * d.idx_stride];
         }
     }
-    template <int KIND>
+    template <int KIND, bool MASK = false>
     __device__ __forceinline__ void store_fast(float* lds, int tid, int i0 = 0, int i1 = NV) const {
 #ifdef NCX_ABLATE_STORES         // timing experiment only
         return;
@@ -305,6 +305,11 @@ struct OpLoader {
             } else if (KIND == X_SOFTMAX) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[j], 1.44269504088896341f, -mx[ri]));
+            }
+            if (COLK && MASK) {             // rows beyond the matrix (M / N edge tiles): clamped pointers, zeroed here
+                const bool rv = (rowmask >> i) & 1u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = rv ? v[j] : 0.f;
             }
             float* dst = COLK ? lds + (i * 32 + (tid >> 3)) * PITCH + 4 * (tid & 7)
                               : lds + (tid >> 3) * PITCH + 4 * (tid & 7) + 32 * i;
@@ -532,8 +537,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
     // has nobody else to hide its stalls):
     //   global loads of tile t+1  |  sub-steps 0..2: fragment reads run one sub-step ahead of their MFMAs  |
     //   sub-step 3's MFMAs interleaved with the transform (exp2 / product) + ds_write of tile t+1  |  barrier
-    auto fast_run = [&](auto akind_c, auto bkind_c, int nfast, int& buf) {
+    auto fast_run = [&](auto akind_c, auto bkind_c, auto mask_c, int nfast, int& buf) {
         constexpr int AK = decltype(akind_c)::value, BKD = decltype(bkind_c)::value;
+        constexpr bool MK = decltype(mask_c)::value;
         const XDesc& da = adesc(seg);
         const XDesc& db = args.b[seg];
         for (int it = 0; it < nfast; ++it) {
@@ -574,8 +580,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
             }
             __builtin_amdgcn_sched_barrier(0);
             // sub-step 3: transform (exp2 / product) + ds_write of tile t+1 in the MFMA shadows
-            la.template store_fast<AK>(lds_a + (buf ^ 1) * Cfg::A_ELEMS, tid);
-            lb.template store_fast<BKD>(lds_b + (buf ^ 1) * Cfg::B_ELEMS, tid);
+            la.template store_fast<AK, MK>(lds_a + (buf ^ 1) * Cfg::A_ELEMS, tid);
+            lb.template store_fast<BKD, MK>(lds_b + (buf ^ 1) * Cfg::B_ELEMS, tid);
             mfma_frags(af1, bf1);
 #pragma unroll
             for (int q = 0; q < NMFMA; ++q) {
@@ -592,8 +598,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
     // issued while tile t is multiplied and tile t+1 (loaded a whole k-step ago, so never waited for) is
     // transformed and written to LDS spread over sub-steps 1 and 2.  Measured by ablation on the depth-1 loop:
     // load waits and the clustered store phase cost ~10 % each.
-    auto fast_run2 = [&](auto akind_c, auto bkind_c, int nfast, int& buf) {
+    auto fast_run2 = [&](auto akind_c, auto bkind_c, auto mask_c, int nfast, int& buf) {
         constexpr int AK = decltype(akind_c)::value, BKD = decltype(bkind_c)::value;
+        constexpr bool MK = decltype(mask_c)::value;
         const XDesc& da = adesc(seg);
         const XDesc& db = args.b[seg];
         typename Cfg::ALoad la2 = la;
@@ -628,8 +635,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
             }
             __builtin_amdgcn_sched_barrier(0);
             read_frags(pa, pb, 2, af0, bf0);
-            sa.template store_fast<AK>(wa, tid, 0, (NVA + 1) / 2);
-            sb.template store_fast<BKD>(wb, tid, 0, (NVB + 1) / 2);
+            sa.template store_fast<AK, MK>(wa, tid, 0, (NVA + 1) / 2);
+            sb.template store_fast<BKD, MK>(wb, tid, 0, (NVB + 1) / 2);
             mfma_frags(af1, bf1);
 #pragma unroll
             for (int q = 0; q < NMFMA; ++q) {
@@ -640,8 +647,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
             }
             __builtin_amdgcn_sched_barrier(0);
             read_frags(pa, pb, 3, af1, bf1);
-            sa.template store_fast<AK>(wa, tid, (NVA + 1) / 2, NVA);
-            sb.template store_fast<BKD>(wb, tid, (NVB + 1) / 2, NVB);
+            sa.template store_fast<AK, MK>(wa, tid, (NVA + 1) / 2, NVA);
+            sb.template store_fast<BKD, MK>(wb, tid, (NVB + 1) / 2, NVB);
             mfma_frags(af0, bf0);
 #pragma unroll
             for (int q = 0; q < NMFMA; ++q) {
@@ -665,11 +672,21 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
         lb.prefetch_rows(db, kpos + BK, tid);
     };
     constexpr bool DEPTH2 = BM * BN >= 96 * 128;
+    // M / N edge tiles of col-is-k operands run the same fast path with the row mask compiled in (MAIN pays ~4 % for
+    // it, so interior tiles get the mask-free variant)
+    const bool edge_rows = (A_COLK && m0 + BM > M) || (B_COLK && n0 + BN > N);
     auto fast_dispatch = [&](auto akind_c, auto bkind_c, int nfast, int& buf) {
-        if constexpr (DEPTH2) fast_run2(akind_c, bkind_c, nfast, buf);
-        else fast_run(akind_c, bkind_c, nfast, buf);
+        if (edge_rows) {
+            if constexpr (DEPTH2) fast_run2(akind_c, bkind_c, std::true_type{}, nfast, buf);
+            else fast_run(akind_c, bkind_c, std::true_type{}, nfast, buf);
+        } else {
+            if constexpr (DEPTH2) fast_run2(akind_c, bkind_c, std::false_type{}, nfast, buf);
+            else fast_run(akind_c, bkind_c, std::false_type{}, nfast, buf);
+        }
     };
-    const bool tile_interior = m0 + BM <= M && n0 + BN <= N && args.pad_ == 0;      // pad_ != 0: force the generic path (diagnostics)
+    // The fast path needs every operand tile to be "regular": col-is-k operands only need full K-steps (rows beyond
+    // the matrix are masked in store_fast), row-is-k operands also need their column range inside the matrix.
+    const bool tile_interior = (A_COLK || m0 + BM <= M) && (B_COLK || n0 + BN <= N) && args.pad_ == 0;   // pad_ != 0: diagnostics
 
     // ---- main loop ------------------------------------------------------------------------------
     if (step_begin < step_end) {
