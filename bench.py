@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--K", type=int, default=24)
     ap.add_argument("--n_img", type=int, default=82783)
     ap.add_argument("--pool", type=int, default=4, help="distinct resident batches cycled through")
+    ap.add_argument("--c3", action="store_true", help="configs[2]: z / answer logits produced per step by the fused HIP MUTAN (ncx_vqa_forward)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -126,8 +127,22 @@ def main():
         pool.append(data.batch(torch.arange(lo, lo + args.batch)))
     gb = args.batch * world
 
+    mutan = None
+    if args.c3:
+        # random-init frozen MutanNoAtt of the options/cx/*.yaml shape (dim_hv = dim_hq = dim_mm = 360, R = 10, tanh)
+        import vqa.models as M
+        from neuralcx import ops
+        opt = dict(arch="MutanNoAtt", seq2vec=dict(arch="gru", emb_size=8, dropout=0.0),
+                   fusion=dict(dim_v=2048, dim_q=2400, dim_hv=360, dim_hq=360, dim_mm=360, R=10, dropout_v=0.5, dropout_q=0.5,
+                               activation_v="tanh", activation_q="tanh", dropout_hv=0, dropout_hq=0), classif=dict(dropout=0.5))
+        torch.manual_seed(42)
+        vqa_model = M.factory(opt, ["w"], ["a%d" % i for i in range(2000)], cuda=True, data_parallel=False).eval()
+        mutan = ops.MutanWeights(vqa_model)
+
     def step(i):
         b, gt = pool[i % args.pool]
+        if mutan is not None:                       # configs[2]: the producer runs inside the timed step
+            b = eng.make_batch_from_vqa(b.feats, b.img_idx, b.q_emb, b.answer_aids, mutan)
         return eng.train_step(b, gt, global_batch=gb)
 
     def fence():
@@ -188,7 +203,8 @@ def main():
                    value=round(gb * args.steps / dt, 1), unit="triplets/s", n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True,
                    scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                   config=dict(workload="configs[1]: NeuralCX MLP train step (fwd+listwise loss/recall+bwd+Adam), synthetic "
+                   config=dict(workload=("configs[2]: fused HIP MUTAN producer (vqa_forward) + " if args.c3 else "configs[1]: ") +
+                                        "NeuralCX MLP train step (fwd+listwise loss/recall+bwd+Adam), synthetic "
                                         "2048-d feats, %d candidates, batch %d per GPU, H=%d, L=%d, dropout 0.25, fp32"
                                         % (c["K"], args.batch, c["H"], c["L"]),
                                global_batch=gb, candidates=c["K"], dim_h=c["H"], n_layers=c["L"],

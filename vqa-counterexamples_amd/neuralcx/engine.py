@@ -136,3 +136,12 @@ class NeuralCXEngine:
         ops.adam_step(self.params.flat, self.grads.flat, self.exp_avg, self.exp_avg_sq, self.step_count, lr=self.lr)
         r["scores"] = scores
         return r
+
+
+    # ---- configs[2]: MUTAN multimodal features produced on the fly ---------------------------------
+    def make_batch_from_vqa(self, feats, img_idx, q_emb, answer_aids, mutan_weights):
+        """Inputs of NeuralCX from the frozen MUTAN producer (ncx_vqa_forward) instead of precomputed z / a blocks."""
+        if getattr(self, "_vqa_ws", None) is None:
+            self._vqa_ws = None
+        _, z_o, a_k, z_k = ops.vqa_forward(feats, img_idx, q_emb, mutan_weights, want_a_orig=False)
+        return ops.Batch(feats, img_idx, q_emb, z_o, z_k, a_k, answer_aids)
