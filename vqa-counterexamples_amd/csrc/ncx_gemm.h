@@ -259,7 +259,7 @@ struct OpLoader {
 
     // ---- interior fast path: no bounds handling, kind compile-time, straight-line -------------------
     // KIND: COLK operands have their row pointers resolved in setup(), so X_GATHER == X_PLAIN there.
-    template <int KIND>
+    template <int KIND, bool MASK = false>
     __device__ __forceinline__ void issue_fast(const XDesc& d, int k, int tid, int idx_ahead = GEMM_BK) {
 #ifdef NCX_ABLATE_LOADS          // timing experiment only: keep the registers of the first tile
         return;
@@ -279,11 +279,12 @@ struct OpLoader {
             else p0[0] = d.base + (long long)r * d.ld;
             if (KIND == X_GATHER_MUL) p1[0] = d.base + (long long)nidx1 * d.ld;
             if (KIND == X_SOFTMAX) { mx[0] = d.mx[r]; }
+            // MASK (column-edge tile): windows slid left to stay inside the row, repaired in store_fast
 #pragma unroll
-            for (int i = 0; i < NV; ++i) v0[i] = *(const f32x4u*)(p0[0] + c + 32 * i);
+            for (int i = 0; i < NV; ++i) v0[i] = MASK ? load_window(p0[0], c + 32 * i, cols) : *(const f32x4u*)(p0[0] + c + 32 * i);
             if (KIND == X_GATHER_MUL) {
 #pragma unroll
-                for (int i = 0; i < NV; ++i) v1[i] = *(const f32x4u*)(p1[0] + c + 32 * i);
+                for (int i = 0; i < NV; ++i) v1[i] = MASK ? load_window(p1[0], c + 32 * i, cols) : *(const f32x4u*)(p1[0] + c + 32 * i);
             }
             // gather indices of this loader's next k-step
             if (KIND == X_GATHER || KIND == X_GATHER_MUL) nidx0 = d.idx[(long long)(min(r + idx_ahead, rows - 1)) * d.idx_stride];
@@ -306,6 +307,7 @@ struct OpLoader {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[j], 1.44269504088896341f, -mx[ri]));
             }
+            if (!COLK && MASK) v = fix_window(v, o0 + 4 * (tid & 7) + 32 * i, cols);   // column-edge tile
             if (COLK && MASK) {             // rows beyond the matrix (M / N edge tiles): clamped pointers, zeroed here
                 const bool rv = (rowmask >> i) & 1u;
 #pragma unroll
@@ -551,8 +553,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
             __builtin_amdgcn_sched_barrier(0);
             // sub-step 0: its MFMAs carry the global loads of tile t+1 (one address add + one load per gap) and
             // the fragment reads of sub-step 1 -- with one wave per SIMD only what sits BETWEEN two MFMAs is hidden
-            la.template issue_fast<AK>(da, kpos, tid);
-            lb.template issue_fast<BKD>(db, kpos, tid);
+            la.template issue_fast<AK, MK>(da, kpos, tid);
+            lb.template issue_fast<BKD, MK>(db, kpos, tid);
             read_frags(pa, pb, 1, af1, bf1);
             mfma_frags(af0, bf0);
 #pragma unroll
@@ -605,8 +607,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
         const XDesc& db = args.b[seg];
         typename Cfg::ALoad la2 = la;
         typename Cfg::BLoad lb2 = lb;
-        la.template issue_fast<AK>(da, kpos + BK, tid, 2 * BK);        // tile t+1 (indices prefetched by the caller)
-        lb.template issue_fast<BKD>(db, kpos + BK, tid, 2 * BK);
+        la.template issue_fast<AK, MK>(da, kpos + BK, tid, 2 * BK);        // tile t+1 (indices prefetched by the caller)
+        lb.template issue_fast<BKD, MK>(db, kpos + BK, tid, 2 * BK);
         la2.prefetch_rows(da, kpos + 2 * BK, tid);
         lb2.prefetch_rows(db, kpos + 2 * BK, tid);
         auto body = [&](auto issue_c, typename Cfg::ALoad& sa, typename Cfg::BLoad& sb, typename Cfg::ALoad& ia, typename Cfg::BLoad& ib) {
@@ -621,8 +623,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
             read_frags(pa, pb, 0, af0, bf0);
             __builtin_amdgcn_sched_barrier(0);
             if (ISSUE) {
-                ia.template issue_fast<AK>(da, kpos + BK, tid, 2 * BK);
-                ib.template issue_fast<BKD>(db, kpos + BK, tid, 2 * BK);
+                ia.template issue_fast<AK, MK>(da, kpos + BK, tid, 2 * BK);
+                ib.template issue_fast<BKD, MK>(db, kpos + BK, tid, 2 * BK);
             }
             read_frags(pa, pb, 1, af1, bf1);
             mfma_frags(af0, bf0);
@@ -674,7 +676,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
     constexpr bool DEPTH2 = BM * BN >= 96 * 128;
     // M / N edge tiles of col-is-k operands run the same fast path with the row mask compiled in (MAIN pays ~4 % for
     // it, so interior tiles get the mask-free variant)
-    const bool edge_rows = (A_COLK && m0 + BM > M) || (B_COLK && n0 + BN > N);
+    const bool edge_rows = m0 + BM > M || n0 + BN > N;
     auto fast_dispatch = [&](auto akind_c, auto bkind_c, int nfast, int& buf) {
         if (edge_rows) {
             if constexpr (DEPTH2) fast_run2(akind_c, bkind_c, std::true_type{}, nfast, buf);
@@ -684,9 +686,9 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
             else fast_run(akind_c, bkind_c, std::false_type{}, nfast, buf);
         }
     };
-    // The fast path needs every operand tile to be "regular": col-is-k operands only need full K-steps (rows beyond
-    // the matrix are masked in store_fast), row-is-k operands also need their column range inside the matrix.
-    const bool tile_interior = (A_COLK || m0 + BM <= M) && (B_COLK || n0 + BN <= N) && args.pad_ == 0;   // pad_ != 0: diagnostics
+    // The fast path only needs full K-steps: M / N edge tiles run its masked variant (col-is-k operands: rows beyond the
+    // matrix zeroed; row-is-k operands: column windows clamped and repaired).
+    const bool tile_interior = args.pad_ == 0;                                          // pad_ != 0: diagnostics
 
     // ---- main loop ------------------------------------------------------------------------------
     if (step_begin < step_end) {
