@@ -409,20 +409,20 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
     const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
 
     const int M = args.M;
-    f32x4 acc[WM][WN];
-    f32x4 zacc[FOLD ? WM : 1][FOLD ? WN : 1];
-    if (FOLD) {
-#pragma unroll
-        for (int i = 0; i < (FOLD ? WM : 1); ++i)
-#pragma unroll
-            for (int j = 0; j < (FOLD ? WN : 1); ++j) zacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
   // Optional persistent loop (NCX_PERSISTENT=1; default: one workgroup per item): the grid holds at most one workgroup per resident slot (a multiple of 8, so item % 8 -- the XCD
   // affinity WgMap is built on -- is the same for every item of a workgroup); a slot then never idles between the
   // exit of one short workgroup and the dispatch of the next.
   for (int item = blockIdx.x; item < args.total_wgs; item += gridDim.x) {
     // ---- which problem / tile / k-chunk -------------------------------------------------------------
     // Work items of problem p: w = wg0[p] + WgMap::encode(tm, tn, z) (XCD-aware order, see WgMap).
+    // (accumulators are declared per item: hoisted out of this loop the 16-vector array of the 128x128 tile was
+    // kept in scratch memory -- 32 scratch accesses per k-step, 45 instead of 116 TFLOP/s)
+    f32x4 acc[WM][WN];
+    f32x4 zacc[FOLD ? WM : 1][FOLD ? WN : 1];
+#pragma unroll
+    for (int i = 0; i < (FOLD ? WM : 1); ++i)
+#pragma unroll
+        for (int j = 0; j < (FOLD ? WN : 1); ++j) zacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     int prob = 0, lw = item;
     if (args.mode == MODE_GROUP) {
         while (prob + 1 < args.nseg && lw >= args.wg0[prob + 1]) ++prob;
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
 
     typename Cfg::ALoad la;
     typename Cfg::BLoad lb;
-    auto adesc = [&](int s) -> const XDesc& { return args.a[s]; };
+    auto adesc = [&](int s) __attribute__((always_inline)) -> const XDesc& { return args.a[s]; };
 
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -468,11 +468,11 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
     // columns.  Col-is-k operands keep contiguous 16-row blocks (one ds_read_b64 per block and k-pair).
     constexpr bool A_IL = !A_COLK && (WM == 4 || WM == 2);
     constexpr bool B_IL = !B_COLK && (WN == 4 || WN == 2);
-    auto trow = [&](int qa, int r) { return A_IL ? wm0 + WM * r + qa : wm0 + 16 * qa + r; };   // tile-local row
-    auto tcol = [&](int qb, int c) { return B_IL ? wn0 + WN * c + qb : wn0 + 16 * qb + c; };   // tile-local col
+    auto trow = [&](int qa, int r) __attribute__((always_inline)) { return A_IL ? wm0 + WM * r + qa : wm0 + 16 * qa + r; };   // tile-local row
+    auto tcol = [&](int qb, int c) __attribute__((always_inline)) { return B_IL ? wn0 + WN * c + qb : wn0 + 16 * qb + c; };   // tile-local col
 
     // LDS -> register fragments of sub-step t (8 k-values: two MFMAs per accumulator)
-    auto read_frags = [&](const float* pa, const float* pb, int t, f32x2 (&af)[WM], f32x2 (&bf)[WN]) {
+    auto read_frags = [&](const float* pa, const float* pb, int t, f32x2 (&af)[WM], f32x2 (&bf)[WN]) __attribute__((always_inline)) {
         const int kk = t * 8 + 2 * lk;
         if (A_COLK) {
 #pragma unroll
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
             for (int j = 0; j < WN; ++j) bf[j] = f32x2{pb[kk * PB + wn0 + j * 16 + li], pb[(kk + 1) * PB + wn0 + j * 16 + li]};
         }
     };
-    auto mfma_frags = [&](const f32x2 (&af)[WM], const f32x2 (&bf)[WN]) {
+    auto mfma_frags = [&](const f32x2 (&af)[WM], const f32x2 (&bf)[WN]) __attribute__((always_inline)) {
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
     // k order inside a 32-deep step: MFMA (t, e) takes k = 8t + 2*lk + e from lane group lk, for BOTH operands
     // (any bijection works as long as A and B agree).  A col-is-k tile then serves two MFMAs per ds_read_b64
     // (pitch 36: 36*i mod 64 hits 16 distinct multiples of 4, + 2*lk + e: conflict-free over a 32-lane half).
-    auto compute_range = [&](int buf, int t0, int t1) {
+    auto compute_range = [&](int buf, int t0, int t1) __attribute__((always_inline)) {
         const float* pa = lds_a + buf * Cfg::A_ELEMS;
         const float* pb = lds_b + buf * Cfg::B_ELEMS;
 #pragma unroll
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
             mfma_frags(af, bf);
         }
     };
-    auto compute = [&](int buf) { compute_range(buf, 0, BK / 8); };
+    auto compute = [&](int buf) __attribute__((always_inline)) { compute_range(buf, 0, BK / 8); };
     constexpr int NREADS = (A_COLK ? WM : A_IL ? 2 : 2 * WM) + (B_COLK ? WN : B_IL ? 2 : 2 * WN);   // ds_read instructions per sub-step
     constexpr int NMFMA = 2 * WM * WN;                                          // MFMAs per sub-step
 
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
     // has nobody else to hide its stalls):
     //   global loads of tile t+1  |  sub-steps 0..2: fragment reads run one sub-step ahead of their MFMAs  |
     //   sub-step 3's MFMAs interleaved with the transform (exp2 / product) + ds_write of tile t+1  |  barrier
-    auto fast_run = [&](auto akind_c, auto bkind_c, auto mask_c, int nfast, int& buf) {
+    auto fast_run = [&](auto akind_c, auto bkind_c, auto mask_c, int nfast, int& buf) __attribute__((always_inline)) {
         constexpr int AK = decltype(akind_c)::value, BKD = decltype(bkind_c)::value;
         constexpr bool MK = decltype(mask_c)::value;
         const XDesc& da = adesc(seg);
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
     // issued while tile t is multiplied and tile t+1 (loaded a whole k-step ago, so never waited for) is
     // transformed and written to LDS spread over sub-steps 1 and 2.  Measured by ablation on the depth-1 loop:
     // load waits and the clustered store phase cost ~10 % each.
-    auto fast_run2 = [&](auto akind_c, auto bkind_c, auto mask_c, int nfast, int& buf) {
+    auto fast_run2 = [&](auto akind_c, auto bkind_c, auto mask_c, int nfast, int& buf) __attribute__((always_inline)) {
         constexpr int AK = decltype(akind_c)::value, BKD = decltype(bkind_c)::value;
         constexpr bool MK = decltype(mask_c)::value;
         const XDesc& da = adesc(seg);
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
         lb.template issue_fast<BKD, MK>(db, kpos + BK, tid, 2 * BK);
         la2.prefetch_rows(da, kpos + 2 * BK, tid);
         lb2.prefetch_rows(db, kpos + 2 * BK, tid);
-        auto body = [&](auto issue_c, typename Cfg::ALoad& sa, typename Cfg::BLoad& sb, typename Cfg::ALoad& ia, typename Cfg::BLoad& ib) {
+        auto body = [&](auto issue_c, typename Cfg::ALoad& sa, typename Cfg::BLoad& sb, typename Cfg::ALoad& ia, typename Cfg::BLoad& ib) __attribute__((always_inline)) {
             constexpr bool ISSUE = decltype(issue_c)::value;
             kpos += BK;                                                  // kpos = tile being stored (t+1)
             const float* pa = lds_a + buf * Cfg::A_ELEMS;
@@ -673,11 +673,11 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
         la.prefetch_rows(da, kpos + BK, tid);                            // re-arm the generic path's index prefetch
         lb.prefetch_rows(db, kpos + BK, tid);
     };
-    constexpr bool DEPTH2 = BM * BN >= 96 * 128;
+    constexpr bool DEPTH2 = BM == 96 && BN == 128;      // 128x128 would need > 512 VGPRs (it spilled: 31 TFLOP/s at B=2048)
     // M / N edge tiles of col-is-k operands run the same fast path with the row mask compiled in (MAIN pays ~4 % for
     // it, so interior tiles get the mask-free variant)
     const bool edge_rows = m0 + BM > M || n0 + BN > N;
-    auto fast_dispatch = [&](auto akind_c, auto bkind_c, int nfast, int& buf) {
+    auto fast_dispatch = [&](auto akind_c, auto bkind_c, int nfast, int& buf) __attribute__((always_inline)) {
         if (edge_rows) {
             if constexpr (DEPTH2) fast_run2(akind_c, bkind_c, std::true_type{}, nfast, buf);
             else fast_run(akind_c, bkind_c, std::true_type{}, nfast, buf);
@@ -812,8 +812,21 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
     float bias_v[WN];
 #pragma unroll
     for (int j = 0; j < WN; ++j) bias_v[j] = e.bias ? e.bias[min(n0 + tcol(j, li), N - 1)] : 0.f;
-#pragma unroll
+    // 4x4-block tiles: the row-block loop stays rolled (fully unrolled it exceeds the unroller's size limit, which
+    // left acc[] dynamically indexed -> the whole accumulator array lived in scratch); the block's accumulators
+    // are picked with compile-time-indexed selects instead.
+    constexpr bool EPI_ROLL = WM * WN >= 16;
+#pragma unroll(EPI_ROLL ? 1 : WM)
     for (int i = 0; i < WM; ++i) {
+        f32x4 accrow[WN];
+#pragma unroll
+        for (int ii = 0; ii < WM; ++ii)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const f32x4 src = FOLD ? zacc[FOLD ? ii : 0][FOLD ? j : 0] : acc[ii][j];
+                if (ii == 0) accrow[j] = src;
+                else accrow[j] = (ii == i) ? src : accrow[j];
+            }
         float addv[WN][4], gatev[WN][4], maskv[WN][4];
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
@@ -832,7 +845,7 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = m0 + trow(i, lk * 4 + q);
-                float v = (FOLD ? zacc[FOLD ? i : 0][FOLD ? j : 0][q] : acc[i][j][q]) + addv[j][q] + bias_v[j];
+                float v = accrow[j][q] + addv[j][q] + bias_v[j];
                 if (e.relu == 1) v = v > 0.f ? v : 0.f;
                 else if (e.relu == 2) v = tanhf(v);
                 if (e.dropout == 1)
