@@ -135,6 +135,50 @@ def test_cli_synthetic_smoke(tmp_path, capsys):
     assert os.path.exists(os.path.join(base, "final_results.txt"))
 
 
+def test_cli_real_data_mode_on_reference_format_files(tmp_path, capsys):
+    """the CLI's default (real-data) mode on files in the reference's on-disk formats -- pickles, feature
+    tables, answer embedding -- kept resident on the device; the per-batch pipeline (index slices -> question encoder ->
+    ncx_vqa_forward -> NeuralCX) must agree with the NeuralModel module fed the reference's dense batch."""
+    import counterexamples as cli
+    from neuralcx import formats
+    from vqa.models.cx import NeuralModel
+    paths = formats.write_synthetic_cx_files(os.path.join(str(tmp_path), "data"), n_train=192, n_val=96, n_img=300, seed=5)
+    argv = ["--path_opt", os.path.join(PKG, "options", "cx", "neuralcx_256_1_all.yaml"), "-b", "64", "--epochs", "2", "-p", "2",
+            "-t", "--untrained_vqa", "--project_dir", str(tmp_path), "--path_trainset", paths["path_trainset"],
+            "--path_features", paths["path_features"]]
+    cli.main(argv)
+    out = capsys.readouterr().out
+    assert "Epoch 2 train: loss:" in out and "Epoch 2 val: loss:" in out and "test:" in out
+    base = os.path.join(str(tmp_path), "logs", "cx")
+    base = os.path.join(base, os.listdir(base)[0])
+    state = torch.load(os.path.join(base, "best", "model.ckpt"))
+    assert state["linear_1.weight"].shape == (256, 14089) and any(k.startswith("vqa_model.") for k in state)
+    assert os.path.exists(os.path.join(base, "final_results.txt"))
+    # the answer embedding was initialised from answer_embedding.pickle (counterexamples.py:250-253): still close to it
+    emb = formats.load_answer_embedding(os.path.join(paths["path_trainset"], "answer_embedding.pickle"))
+    assert float((state["answer_embedding.weight"] - torch.from_numpy(emb)).abs().max()) < 1e-2
+
+    # same checkpoint through the drop-in module with the reference's dense inputs (getDataFromBatch layout)
+    args = cli.build_parser().parse_args(argv)
+    r = cli.Runner(args, cli.load_options(args))
+    r.load_real()
+    r.engine.load_state({k: v for k, v in state.items() if not k.startswith("vqa_model.")})
+    r.vqa.load_state_dict({k[len("vqa_model."):]: v for k, v in state.items() if k.startswith("vqa_model.")})
+    r.mutan = type(r.mutan)(r.vqa)
+    ids = list(range(40))
+    b, gt = r.get_batch(r.val, ids)
+    ev = r.engine.eval_step(b, gt)
+    opt = cli.load_options(args)
+    m = NeuralModel(model_spec=opt["cx_model"], dim_h=256, n_layers=1, emb=None, drop_p=0.25, vqa_model=r.vqa, knn_size=24,
+                    trainable_vqa=False).cuda()
+    m.load_state_dict(state)
+    m.eval()
+    img_idx, wids, aids, gt2 = r.val.batch_indices(torch.tensor(ids))
+    scores = m(r.val.dense_features(img_idx), wids, aids.long())
+    assert float((scores.detach() - ev["scores"]).abs().max()) <= 1e-4
+    assert torch.equal(gt, gt2)
+
+
 def _dp_gpu_worker(rank, world, port, q):
     import os, sys
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")

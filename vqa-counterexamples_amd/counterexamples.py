@@ -10,9 +10,13 @@ Net-new: `--synthetic` (no datasets offline: synthetic feature table + triplets 
 parallelism: launch with `python -m torch.distributed.run --nproc-per-node N counterexamples.py ...`;
 every rank holds the feature table and a replica, gradients are summed over RCCL.
 
-Real-data mode expects what the reference's notebooks produce (trainset_augmented.pickle, valset_augmented*.pickle,
-{train,val}set.npy feature tables converted from the hdf5 files, since h5py is not available here) plus a trained
-VQA checkpoint; it is wired but cannot be exercised in this offline image.
+Real-data mode (default, as in the reference) reads what the reference's notebooks produce -- `<vqa.path_trainset>/
+pickle_old/{trainset_augmented[_small],valset_augmented_small,valset_augmented}.pickle`, `<coco.path_features>/
+{train,val}set.{npy|hdf5}` (hdf5 needs h5py; neuralcx.formats.convert_hdf5_features converts once), optional
+`answer_embedding.pickle` and the VQA checkpoint `<logs.dir_logs>/best_model.pth.tar` -- ONCE, keeps the feature tables
+and index arrays resident in HBM (neuralcx.formats.CXDeviceDataset) and produces q / z / a per batch with the frozen VQA
+model (question encoder in PyTorch, MUTAN fusion + classifier in ncx_vqa_forward).  No real datasets exist offline:
+tests drive this mode with files written by neuralcx.formats.write_synthetic_cx_files.
 """
 import argparse
 import json
@@ -33,9 +37,11 @@ if HERE not in sys.path:
 
 import vqa.lib.utils as utils                     # noqa: E402
 import vqa.models as models                       # noqa: E402
+from vqa.models.cx import CXModelBase             # noqa: E402
 from neuralcx import dp, ops                      # noqa: E402
 from neuralcx.engine import NeuralCXEngine        # noqa: E402
 from neuralcx.synth import SyntheticCX            # noqa: E402
+from neuralcx import formats                      # noqa: E402
 
 
 def build_parser():
@@ -66,6 +72,8 @@ def build_parser():
     p.add_argument("--syn_val", type=int, default=4096)
     p.add_argument("--syn_images", type=int, default=82783)
     p.add_argument("--max_steps", type=int, default=-1, help="stop an epoch early (smoke runs)")
+    p.add_argument("--path_trainset", type=str, default=None, help="overrides vqa.path_trainset of the YAML")
+    p.add_argument("--path_features", type=str, default=None, help="overrides coco.path_features / path_raw of the YAML")
     return p
 
 
@@ -114,6 +122,62 @@ class Runner:
         n_tr = 1024 if a.dev_mode else a.syn_train
         self.train = SyntheticCX(n_triplets=n_tr, n_img=a.syn_images, seed=1234, **kw)
         self.val = SyntheticCX(n_triplets=a.syn_val, n_img=a.syn_images, seed=4321, feats=self.train.feats, **kw)
+        self.test = self.val
+        self.vqa = None
+
+    def load_real(self):
+        """counterexamples.py:181-262: pickles, feature tables, VQA model (+ checkpoint), answer embedding -- loaded once
+        and kept on the device."""
+        a, opt = self.args, self.opt
+        vqa_dir = a.path_trainset or opt["vqa"].get("path_trainset")
+        feat_dir = a.path_features or opt["coco"].get("path_features") or opt["coco"].get("path_raw")
+        if not vqa_dir or not feat_dir:
+            raise SystemExit("real-data mode needs vqa.path_trainset and coco.path_features (YAML or --path_trainset/--path_features)")
+        pk = lambda fn: formats.load_cx_pickle(os.path.join(vqa_dir, "pickle_old", fn))
+        self.log("=> Loading VQA dataset...")
+        trainset = pk("trainset_augmented_small.pickle" if a.dev_mode else "trainset_augmented.pickle")
+        valset = pk("valset_augmented_small.pickle")
+        self.log("=> Loading COCO image features...")
+        self.train = formats.CXDeviceDataset(trainset, formats.load_feature_table(feat_dir, "train"), self.dev, self.K)
+        self.val = formats.CXDeviceDataset(valset, formats.load_feature_table(feat_dir, "val"), self.dev, self.K)
+        self.test = (formats.CXDeviceDataset(pk("valset_augmented.pickle"), None, self.dev, self.K, feats=self.val.feats)
+                     if a.test else self.val)
+        self.log("=> Building model...")
+        self.vqa = models.factory(opt["model"], trainset["vocab_words"], trainset["vocab_answers"], cuda=True, data_parallel=False)
+        if opt["cx_model"].get("pretrained_vqa"):
+            ck = os.path.join(opt["logs"]["dir_logs"], "best") + "_model.pth.tar"          # train.py:332-357
+            if os.path.isfile(ck):
+                self.vqa.load_state_dict(torch.load(ck, map_location=self.dev))
+            else:
+                self.log("Warning: no VQA checkpoint at '{}' (continuing with the untrained VQA model)".format(ck))
+        self.vqa.eval()                                                                      # cx.py:73-80 (frozen)
+        for p_ in self.vqa.parameters():
+            p_.requires_grad_(False)
+        self.mutan = ops.MutanWeights(self.vqa) if isinstance(self.vqa, models.MutanNoAtt) else None
+        self._torch_vqa = None if self.mutan is not None else CXModelBase(self.vqa, self.K)
+        emb = None
+        if opt["cx_model"].get("pretrained_emb"):
+            pe = os.path.join(vqa_dir, "answer_embedding.pickle")
+            if os.path.isfile(pe):
+                emb = formats.load_answer_embedding(pe, n_answers=len(trainset["vocab_answers"]))
+            else:
+                self.log("Warning: no answer embedding at '{}' (random initialisation)".format(pe))
+        self.engine.init_parameters(seed=42, emb=emb)
+
+    def get_batch(self, data, mine):
+        """-> (ops.Batch, gt).  Synthetic: generated on device.  Real: index slices of the resident tables, then the
+        frozen VQA model produces q / z / a (the body of vqa_forward, cx.py:64-104)."""
+        sel = torch.tensor(mine)
+        if self.vqa is None:
+            return data.batch(sel)
+        img_idx, wids, aids, gt = data.batch_indices(sel)
+        with torch.no_grad():
+            if self.mutan is not None:
+                q = self.vqa.seq2vec(wids).float().contiguous()
+                return self.engine.make_batch_from_vqa(data.feats, img_idx, q, aids, self.mutan), gt
+            _, z_o, a_k, z_k, q = self._torch_vqa.vqa_forward(data.dense_features(img_idx), wids)
+            return ops.Batch(data.feats, img_idx, q.float().contiguous(), z_o.float().contiguous(),
+                             z_k.float().contiguous(), a_k.float().contiguous(), aids), gt
 
     # ---- loops ----------------------------------------------------------------------------------------------
     def run_epoch(self, epoch):
@@ -127,7 +191,7 @@ class Runner:
             mine = dp.shard(ids, self.rank, self.world)
             if not mine:
                 continue
-            b, gt = tr.batch(torch.tensor(mine))
+            b, gt = self.get_batch(tr, mine)
             r = eng.train_step(b, gt, global_batch=len(ids))
             acc[0] += r["loss"][0].double() * len(ids); acc[1] += r["hits"][1].double(); acc[2] += len(mine)
             seen += len(ids)
@@ -148,7 +212,7 @@ class Runner:
             mine = dp.shard(ids, self.rank, self.world)
             if not mine:
                 continue
-            b, gt = data.batch(torch.tensor(mine))
+            b, gt = self.get_batch(data, mine)
             r = eng.eval_step(b, gt)
             tot[0] += r["loss_rows"].double().sum() * len(mine); tot[1] += r["hits"][0]; tot[2] += r["hits"][1]; tot[3] += len(mine)
         l, h1, h5, n = dp.reduce_metrics(float(tot[0]), int(tot[1]), int(tot[2]), int(tot[3]), self.dev)
@@ -163,7 +227,10 @@ class Runner:
             return
         os.makedirs(os.path.join(save_dir, "ckpt"), exist_ok=True); os.makedirs(os.path.join(save_dir, "best"), exist_ok=True)
         pm, pi = os.path.join(save_dir, "ckpt", "model.ckpt"), os.path.join(save_dir, "ckpt", "info.ckpt")
-        torch.save({k: v.cpu() for k, v in self.engine.state_dict().items()}, pm)
+        state = {k: v.cpu() for k, v in self.engine.state_dict().items()}
+        if self.vqa is not None:                  # the reference's state_dict embeds the VQA model (cx.py:56)
+            state.update({"vqa_model." + k: v.cpu() for k, v in self.vqa.state_dict().items()})
+        torch.save(state, pm)
         torch.save(info, pi)
         if is_best:
             shutil.copyfile(pm, os.path.join(save_dir, "best", "model.ckpt"))
@@ -187,13 +254,13 @@ def main(argv=None):
         raise SystemExit("only --cx_model NeuralModel runs on the HIP path (baselines: vqa.models.cx.RandomBaseline / DistanceBaseline)")
     if args.pairwise or args.viz:
         raise SystemExit("--pairwise / --viz are outside the accelerated path (SURVEY 8: out of scope)")
-    if not args.synthetic:
-        raise SystemExit("real-data mode needs the VQA-CX pickles and feature tables, which are not available offline; "
-                         "use --synthetic")
     r = Runner(args, options)
     run = args.resume or "{}_{}".format(options["cx_model"].get("name", "neuralcx"), time.strftime("%m%d_%H%M%S"))
     save_dir = os.path.join(args.project_dir, "logs", "cx", run)
-    r.load_synthetic()
+    if args.synthetic:
+        r.load_synthetic()
+    else:
+        r.load_real()
     info, start_epoch, best_recall = [], 1, 0.0
     if args.resume:
         info, start_epoch, best_recall = r.load(save_dir, args.best)
@@ -210,7 +277,7 @@ def main(argv=None):
         r.save(save_dir, info, is_best)
     if args.test:
         r.load(save_dir, best=True)
-        res = r.evaluate(r.val)
+        res = r.evaluate(r.test)
         r.report("test", len(info), res)
         if r.rank == 0:
             with open(os.path.join(save_dir, "final_results.txt"), "w") as f:
