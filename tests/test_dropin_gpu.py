@@ -179,6 +179,37 @@ def test_cli_real_data_mode_on_reference_format_files(tmp_path, capsys):
     assert torch.equal(gt, gt2)
 
 
+def test_cli_baseline_scorers(tmp_path, capsys):
+    """RandomBaseline / DistanceBaseline / BlackBox (cx.py:20-44,114-136) evaluated with the on-device
+    Recall@1/@5 kernel.  DistanceBaseline's Recall@k is exactly the fraction of triplets with knn_index < k."""
+    import counterexamples as cli
+    from neuralcx import formats
+    from vqa.models.cx import BlackBox
+    from oracle import ncx_oracle as orc
+    paths = formats.write_synthetic_cx_files(os.path.join(str(tmp_path), "data"), n_train=64, n_val=160, n_img=200, seed=9)
+    common = ["--path_opt", os.path.join(PKG, "options", "cx", "neuralcx_256_1_all.yaml"), "-b", "64", "-t", "--untrained_vqa",
+              "--project_dir", str(tmp_path), "--path_trainset", paths["path_trainset"], "--path_features", paths["path_features"]]
+    val = formats.load_cx_pickle(os.path.join(paths["path_trainset"], "pickle_old", "valset_augmented.pickle"))
+    gt = np.array([e["comp"]["knn_index"] for e in val["examples_list"]])
+    res = cli.main(common + ["--cx_model", "DistanceBaseline"])
+    assert res["recall_5"] == pytest.approx((gt < 5).mean(), abs=1e-12) and res["recall_1"] == pytest.approx((gt < 1).mean(), abs=1e-12)
+    res = cli.main(common + ["--cx_model", "RandomBaseline"])
+    assert 0.05 < res["recall_5"] < 0.45                                       # 5/24 = 0.208 on 160 triplets
+    res = cli.main(common + ["--cx_model", "BlackBox"])
+    # the same scorer as an nn.Module on the reference's dense batch, ranked by the CPU oracle's recallAtK restatement
+    args = cli.build_parser().parse_args(common + ["--cx_model", "BlackBox"])
+    r = cli.Runner(args, cli.load_options(args))
+    r.load_real()
+    bb = BlackBox(r.vqa, 24)
+    hits1 = hits5 = 0
+    for i in range(0, r.test.N, 64):
+        img_idx, wids, aids, g = r.test.batch_indices(torch.arange(i, min(i + 64, r.test.N)))
+        s = bb(r.test.dense_features(img_idx), wids, aids).cpu()
+        hits1 += int(orc.recall_at_k(s, g.cpu().long(), 1).sum()); hits5 += int(orc.recall_at_k(s, g.cpu().long(), 5).sum())
+    assert res["recall_1"] == pytest.approx(hits1 / r.test.N, abs=1e-12) and res["recall_5"] == pytest.approx(hits5 / r.test.N, abs=1e-12)
+    assert "BlackBox: 160 triplets" in capsys.readouterr().out
+
+
 def _dp_gpu_worker(rank, world, port, q):
     import os, sys
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")

@@ -37,7 +37,7 @@ if HERE not in sys.path:
 
 import vqa.lib.utils as utils                     # noqa: E402
 import vqa.models as models                       # noqa: E402
-from vqa.models.cx import CXModelBase             # noqa: E402
+from vqa.models.cx import CXModelBase, blackbox_scores        # noqa: E402
 from neuralcx import dp, ops                      # noqa: E402
 from neuralcx.engine import NeuralCXEngine        # noqa: E402
 from neuralcx.synth import SyntheticCX            # noqa: E402
@@ -48,7 +48,7 @@ def build_parser():
     p = argparse.ArgumentParser(description="Train/Evaluate NeuralCX counterexample models (MI355X HIP path)")
     p.add_argument("--path_opt", default=os.path.join(HERE, "options", "cx", "neuralcx_256_1_all.yaml"), type=str)
     p.add_argument("--vqa_model", default="mutan_noatt_train", type=str)
-    p.add_argument("--cx_model", default="NeuralModel", type=str, help="NeuralModel | RandomBaseline | DistanceBaseline")
+    p.add_argument("--cx_model", default="NeuralModel", type=str, help="NeuralModel | RandomBaseline | DistanceBaseline | BlackBox")
     p.add_argument("--pairwise", action="store_true")
     p.add_argument("-dev", "--dev_mode", action="store_true", help="small train/val subsets")
     p.add_argument("--pretrained_vqa", dest="pretrained_vqa", action="store_true")
@@ -109,6 +109,7 @@ class Runner:
         self.engine.rank = self.rank
         self.engine.init_parameters(seed=42)
         self.gb = options["optim"]["batch_size"]
+        self.baseline = None if args.cx_model == "NeuralModel" else args.cx_model
 
     def log(self, *a):
         if self.rank == 0:
@@ -213,10 +214,23 @@ class Runner:
             if not mine:
                 continue
             b, gt = self.get_batch(data, mine)
-            r = eng.eval_step(b, gt)
+            r = eng.eval_step(b, gt) if self.baseline is None else self.baseline_step(b, gt)
             tot[0] += r["loss_rows"].double().sum() * len(mine); tot[1] += r["hits"][0]; tot[2] += r["hits"][1]; tot[3] += len(mine)
         l, h1, h5, n = dp.reduce_metrics(float(tot[0]), int(tot[1]), int(tot[2]), int(tot[3]), self.dev)
         return {"loss": l / n, "recall": h5 / n, "recall_1": h1 / n, "recall_5": h5 / n}
+
+    def baseline_step(self, b, gt):
+        """The reference's non-neural scorers (cx.py:20-44,114-136) through the same on-device loss / Recall kernel."""
+        B, K = b.img_idx.shape[0], self.K
+        if self.baseline == "RandomBaseline":
+            scores = torch.rand(B, K, device=self.dev)
+        elif self.baseline == "DistanceBaseline":
+            scores = torch.arange(K - 1, -1, -1, dtype=torch.float32, device=self.dev).repeat(B, 1)
+        else:
+            scores = blackbox_scores(b.a_knns, b.answer_aids).contiguous()
+        r = ops.ranking_loss(scores, gt, want_grad=False)
+        r["scores"] = scores
+        return r
 
     def report(self, mode, epoch, metrics):
         self.log("Epoch {} {}: {}".format(epoch, mode, "".join("{}: {:.4f}, ".format(k, v) for k, v in metrics.items())))
@@ -250,8 +264,9 @@ class Runner:
 def main(argv=None):
     args = build_parser().parse_args(argv)
     options = load_options(args)
-    if args.cx_model != "NeuralModel":
-        raise SystemExit("only --cx_model NeuralModel runs on the HIP path (baselines: vqa.models.cx.RandomBaseline / DistanceBaseline)")
+    if args.cx_model not in ("NeuralModel", "RandomBaseline", "DistanceBaseline", "BlackBox"):
+        raise SystemExit("--cx_model {}: only NeuralModel and the RandomBaseline / DistanceBaseline / BlackBox scorers are "
+                         "provided (the reference's other models are outside the accelerated path)".format(args.cx_model))
     if args.pairwise or args.viz:
         raise SystemExit("--pairwise / --viz are outside the accelerated path (SURVEY 8: out of scope)")
     r = Runner(args, options)
@@ -264,6 +279,20 @@ def main(argv=None):
     info, start_epoch, best_recall = [], 1, 0.0
     if args.resume:
         info, start_epoch, best_recall = r.load(save_dir, args.best)
+    if r.baseline is not None:            # nothing to train (optimizer is None in the reference, :336): evaluate and report
+        t0 = time.time()
+        res = r.evaluate(r.test if args.test else r.val)
+        torch.cuda.synchronize()
+        n = (r.test if args.test else r.val).N
+        r.report("test" if args.test else "val", 1, res)
+        r.log("{}: {} triplets in {:.2f} s ({:.0f} triplets/s)".format(r.baseline, n, time.time() - t0, n / (time.time() - t0)))
+        if r.rank == 0 and args.test:
+            os.makedirs(save_dir, exist_ok=True)
+            with open(os.path.join(save_dir, "final_results.txt"), "w") as f:
+                json.dump(res, f)
+        if torch.distributed.is_initialized():
+            torch.distributed.barrier(); torch.distributed.destroy_process_group()
+        return res
     r.log("=> Starting training... ({} GPU(s), global batch {}, {} train / {} val triplets)".format(
         r.world, r.gb, r.train.N, r.val.N))
     for epoch in range(start_epoch, options["optim"]["epochs"] + 1):

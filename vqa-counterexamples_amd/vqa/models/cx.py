@@ -96,6 +96,25 @@ class CXModelBase(nn.Module):
         raise NotImplementedError
 
 
+def blackbox_scores(a_knns, answer_aids):
+    """-softmax(a_knns)[b, k, answer_aids[b]]: the VQA model's own probability of the original answer on each
+    candidate, sign-flipped because the likeliest images are the worst counterexamples (cx.py:122-136)."""
+    aid = answer_aids.long().view(-1, 1, 1).expand(-1, a_knns.size(1), 1)
+    return -(a_knns.gather(2, aid).squeeze(2) - torch.logsumexp(a_knns, dim=2)).exp()
+
+
+class BlackBox(CXModelBase):
+    """Scores candidates with the frozen VQA model alone (reference cx.py:114-136; README row 'Hard negative mining')."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.vqa_model.eval()
+
+    def forward(self, image_features, question_wids, answer_aids):
+        _, _, a_knns, _, _ = self.vqa_forward(image_features, question_wids)
+        return blackbox_scores(a_knns, answer_aids)
+
+
 class NeuralModel(CXModelBase):
     def __init__(self, model_spec, dim_h, n_layers, emb, drop_p, **kwargs):
         super().__init__(vqa_model=kwargs["vqa_model"], knn_size=kwargs["knn_size"],
