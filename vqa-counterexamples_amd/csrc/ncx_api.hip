@@ -463,14 +463,27 @@ static void list_uses(const ncx_dims& d, GemmUse* u) {
     u[U_DWL]   = {FORM_TN, H, H, ks(M), false};
     u[U_DXL]   = {FORM_NN, M, H, ks(H), false};
     for (int i = 0; i < U_COUNT; ++i) {
-        long long tb = cdiv(u[i].M, 128) * cdiv(u[i].N, 128), ts = cdiv(u[i].M, 64) * cdiv(u[i].N, 64);
-        if (i == U_DW1C || i == U_DW1S) {                       // grouped: tiles are counted per column segment
-            tb = ts = 0;
-            const long long segs_c[5] = {d.dv, (d.flags & NCX_F_V_MULT) ? d.dv : 0, d.K + 1, d.dz, aemb ? d.A : d.da};
-            const long long segs_s[5] = {d.dv, d.dq, d.dz, d.da, 0};
+        // grouped launches (DW1C + DW1S): tiles are counted per column segment
+        const long long segs_c[5] = {d.dv, (d.flags & NCX_F_V_MULT) ? d.dv : 0, d.K + 1, d.dz, aemb ? d.A : d.da};
+        const long long segs_s[5] = {d.dv, d.dq, d.dz, d.da, 0};
+        const bool grouped = i == U_DW1C || i == U_DW1S;
+        auto grouped_tiles = [&](int bm, int bn) {
             const long long* sg = i == U_DW1C ? segs_c : segs_s;
-            for (int q = 0; q < 5; ++q) { tb += cdiv(H, 128) * cdiv(sg[q], 128); ts += cdiv(H, 64) * cdiv(sg[q], 64); }
-            u[i].plan = plan_from_tiles(FORM_TN, tb, ts, u[i].ksteps, false);
+            long long t = 0;
+            for (int q = 0; q < 5; ++q) t += cdiv(H, bm) * cdiv(sg[q], bn);
+            return t;
+        };
+        if (grouped) {
+            u[i].plan = plan_from_tiles(FORM_TN, grouped_tiles(128, 128), grouped_tiles(64, 64), u[i].ksteps, false);
+            // Measured on MI355X (C2, H=256: 206 tiles of 128x64 x 384 k-steps): 128x64 with 6-8 k-chunks 0.448 ms vs
+            // 0.476 ms for 64x64 x 8; three rounds of the 2-per-CU slots.
+            if (i == U_DW1C && H >= 128 && u[i].plan.split > 1) {
+                u[i].plan.cfg = CFG_128x64;
+                const long long slots = (long long)occupancy_tn(CFG_128x64) * num_cus();
+                long long sp = cdiv(3 * slots, grouped_tiles(128, 64));
+                const long long smax = u[i].ksteps / 24 > 1 ? u[i].ksteps / 24 : 1;
+                u[i].plan.split = (int)(sp > smax ? smax : sp < 1 ? 1 : sp);
+            }
         } else {
             u[i].plan = plan_gemm(u[i].form, u[i].M, u[i].N, u[i].ksteps, u[i].allow96);
         }
@@ -486,7 +499,7 @@ static void list_uses(const ncx_dims& d, GemmUse* u) {
         }
         int bm, bn; cfg_tile(u[i].plan.cfg, bm, bn);
         long long tiles = cdiv(u[i].M, bm) * cdiv(u[i].N, bn);
-        if (i == U_DW1C || i == U_DW1S) tiles = u[i].plan.cfg == CFG_128x128 ? tb : ts;
+        if (grouped) tiles = grouped_tiles(bm, bn);
         u[i].tiles = tiles;
         u[i].slab_elems = u[i].plan.split > 1 ? tiles * u[i].plan.split * bm * bn : 0;
     }
@@ -494,6 +507,11 @@ static void list_uses(const ncx_dims& d, GemmUse* u) {
     u[U_DW1S].plan.cfg = u[U_DW1C].plan.cfg;
     {
         int bm, bn; cfg_tile(u[U_DW1C].plan.cfg, bm, bn);
+        u[U_DW1S].tiles = 0;
+        for (int q = 0; q < 4; ++q) {
+            const long long segs_s[4] = {d.dv, d.dq, d.dz, d.da};
+            u[U_DW1S].tiles += cdiv(H, bm) * cdiv(segs_s[q], bn);
+        }
         u[U_DW1C].slab_elems = (u[U_DW1C].tiles * u[U_DW1C].plan.split + u[U_DW1S].tiles * u[U_DW1S].plan.split) * bm * bn;
         u[U_DW1S].slab_elems = 0;
     }
