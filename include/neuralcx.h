@@ -171,6 +171,18 @@ int ncx_vqa_forward(const ncx_dims* d, const float* feats, const int32_t* img_id
                     const ncx_mutan_params* m, void* workspace, size_t workspace_bytes,
                     float* z_orig, float* z_knns, float* a_knns, float* a_orig, void* stream);
 
+/* ---- brute-force k nearest neighbours of feature rows --------------------------------------
+ * Replaces knn.py:41-58 of the reference (sklearn NearestNeighbors(n_neighbors=k).fit(table).kneighbors(queries),
+ * brute force, euclidean).  For each of the nq query rows: the k rows of `table` [n, dv] with the smallest
+ * euclidean distance, ascending (ties by row index), as out_idx [nq, k] int64 and out_dist [nq, k] fp32.
+ * One call handles one block of queries; the workspace holds -|x_j|^2/2 for the table (computed when
+ * norms_ready == 0, reusable by later calls with the same table and workspace) and the nq x n product block.
+ * 1 <= k <= min(n, 120); dv >= 4. */
+size_t ncx_knn_workspace_bytes(int32_t n, int32_t block_rows);
+int ncx_knn(const float* table, int32_t n, const float* queries, int32_t nq, int32_t dv, int32_t k,
+            int32_t norms_ready, void* workspace, size_t workspace_bytes, int64_t* out_idx, float* out_dist,
+            void* stream);
+
 /* ---- diagnostics (bench.py / tests only; the only process-global state, off by default) --------------
  * GEMM ids: 0 Gt = W1[:,a_other].E^T, 1 Sh (shared segments), 2 MAIN (candidate segments, the dominant
  * forward kernel), 3 hidden layer l>=2 forward, 4 dW1 candidate columns (+dGt; the dominant backward

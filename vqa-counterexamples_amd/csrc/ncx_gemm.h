@@ -532,7 +532,6 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
         }
     };
     auto compute = [&](int buf) __attribute__((always_inline)) { compute_range(buf, 0, BK / 8); };
-    constexpr int NREADS = (A_COLK ? WM : A_IL ? 2 : 2 * WM) + (B_COLK ? WN : B_IL ? 2 : 2 * WN);   // ds_read instructions per sub-step
     constexpr int NMFMA = 2 * WM * WN;                                          // MFMAs per sub-step
 
     // One interior k-step with compile-time operand kinds.  Hand-pinned software pipeline (one wave per SIMD
@@ -816,7 +815,8 @@ __global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : 2) void seg_gemm_k
     // left acc[] dynamically indexed -> the whole accumulator array lived in scratch); the block's accumulators
     // are picked with compile-time-indexed selects instead.
     constexpr bool EPI_ROLL = WM * WN >= 16;
-#pragma unroll(EPI_ROLL ? 1 : WM)
+    constexpr int EPI_UNROLL = EPI_ROLL ? 1 : WM;
+#pragma unroll EPI_UNROLL
     for (int i = 0; i < WM; ++i) {
         f32x4 accrow[WN];
 #pragma unroll
