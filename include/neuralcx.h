@@ -131,13 +131,24 @@ int ncx_backward(const ncx_dims* d, const ncx_inputs* in, const ncx_params* p,
                  void* workspace, size_t workspace_bytes, const float* dscores,
                  const ncx_grads* g, void* stream);
 
-/* ncx_backward in two halves, for overlapping the gradient all-reduce of a data-parallel job with compute
- * (net-new: the reference is single-GPU).  phase 1 produces out.*, linear_2/3.*, linear_1.bias and the complete
- * answer_embedding gradient; phase 2 produces linear_1.weight.  Calling 1 then 2 on the same stream and workspace
- * is bit-identical to ncx_backward (phase 0). */
+/* ncx_backward in halves, for overlapping the gradient exchange of a data-parallel job with compute
+ * (net-new: the reference is single-GPU).  Two ways to cut it, each bit-identical to ncx_backward (phase 0) when
+ * both halves run in order on the same stream and workspace:
+ *   phase 1 | 2:  1 = out.*, linear_2/3.*, linear_1.bias and the complete answer_embedding gradient;
+ *                 2 = linear_1.weight.
+ *   phase 3 | 4:  3 = everything except the answer_embedding gradient; it leaves dGt | dGgt (2 x [H, A] fp32, the
+ *                 gradient w.r.t. W1[:, a_emb_other] . E^T and the scattered dSh) in the workspace region
+ *                 ncx_ws_region(NCX_WS_DGT);  4 = answer_embedding gradient = dGt^T . W1ak + dGgt^T . W1agt.
+ *                 The embedding gradient is linear in that region, so a DP job sums the 4 MB region over ranks
+ *                 between 3 and 4 instead of all-reducing the 19 MB [A, da] gradient (every rank then computes the
+ *                 same, complete gradient). */
 int ncx_backward_phase(const ncx_dims* d, const ncx_inputs* in, const ncx_params* p,
                        void* workspace, size_t workspace_bytes, const float* dscores,
                        const ncx_grads* g, int32_t phase, void* stream);
+
+/* Byte offset (from the 256-byte aligned workspace base) and size of a named workspace region. */
+#define NCX_WS_DGT 1
+int ncx_ws_region(const ncx_dims* d, int32_t which, size_t* offset, size_t* bytes);
 
 /* Replaces torch.optim.Adam(...).step() (counterexamples.py:275-276,339) on a flat fp32 buffer:
  * defaults betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad.  `step` is the 1-based step

@@ -15,7 +15,7 @@ SPEC_KEYS = ("v_emb", "v_mult", "v_dist", "v_rank", "q_emb", "a_emb", "z_emb")
 
 def golden_names(prefix=""):
     return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f.startswith(prefix)
-                  and not f.startswith(("g4_", "g7_")))
+                  and f.startswith(("g1_", "g2_", "g3_")))          # model cases (g4 / g7 / g8: loss, data helpers, kNN)
 
 
 def load_golden(name):

@@ -228,7 +228,7 @@ def test_one_train_step_matches_golden_adam():
 
 
 def test_phased_backward_is_bit_identical():
-    """ncx_backward_phase 1 then 2 == ncx_backward (what the data-parallel engine relies on for comm overlap)."""
+    """ncx_backward_phase 1 then 2, and 3 then 4, == ncx_backward (what the data-parallel engine relies on)."""
     from neuralcx import ops
     for L in (1, 2):
         d = orc.Dims(dv=96, dq=64, dz=24, A=40, H=64, L=L)
@@ -248,3 +248,17 @@ def test_phased_backward_is_bit_identical():
         ops.backward(dims, b, p, ws, lr["dscores"], g12, phase=2)
         for k in g0:
             assert torch.equal(g0[k], g12[k]), k
+        # the other cut (3 | 4): everything but the embedding gradient, then the embedding gradient from dGt | dGgt;
+        # scaling that workspace block by 2 in between doubles the embedding gradient exactly (linearity: what DP sums)
+        g34 = {k: torch.full_like(v, float("nan")) for k, v in p.items()}
+        ops.backward(dims, b, p, ws, lr["dscores"], g34, phase=3)
+        for k in g0:
+            if k != "answer_embedding":
+                assert torch.equal(g0[k], g34[k]), k
+        blk = ops.ws_dgt_view(dims, ws)
+        assert blk.numel() == 2 * d.H * d.A
+        ops.backward(dims, b, p, ws, lr["dscores"], g34, phase=4)
+        assert torch.equal(g0["answer_embedding"], g34["answer_embedding"])
+        blk.mul_(2.0)
+        ops.backward(dims, b, p, ws, lr["dscores"], g34, phase=4)
+        assert torch.equal(2.0 * g0["answer_embedding"], g34["answer_embedding"])

@@ -531,8 +531,8 @@ WsLayout ws_layout(const ncx_dims& d) {
     w.dpre[0] = take(M * H * 4);
     w.dpre[1] = d.L >= 2 ? take(M * H * 4) : 0;
     w.dsh = take((size_t)d.B * H * 4);
-    w.dgt = take(H * d.A * 4);
-    w.dagt = take(H * d.A * 4);                         // dGgt[H][A] = one-hot(aid)^T dSh, transposed
+    w.dgt = take(2 * H * d.A * 4);                      // dGt[H][A], then (contiguous: one all-reduce bucket under DP)
+    w.dagt = w.dgt + H * d.A * 4;                       // dGgt[H][A] = one-hot(aid)^T dSh, transposed
     w.partial = take((size_t)NCX_COLSUM_CHUNKS * H * 4 * 2 + (size_t)NCX_COLSUM_CHUNKS * 4 + 256);
     GemmUse u[U_COUNT];
     list_uses(d, u);
@@ -789,12 +789,15 @@ int ncx_backward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, 
 
 int ncx_backward_phase(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, void* workspace,
                        size_t workspace_bytes, const float* dscores, const ncx_grads* g, int32_t phase, void* stream_) {
-    if (phase < 0 || phase > 2) return NCX_E_FLAGS;
+    if (phase < 0 || phase > 4) return NCX_E_FLAGS;
     return backward_impl(dp, in, p, workspace, workspace_bytes, dscores, g, stream_, phase);
 }
 
 // phase 0: everything.  phase 1: out / hidden layers / b1 and the answer_embedding gradient (complete when it
 // returns);  phase 2: linear_1.weight.  1 then 2 == 0 bit for bit (same kernels, the dGt problem launched alone).
+// phase 3: everything except the answer_embedding GEMM (leaves dGt | dGgt in the workspace, ncx_ws_region);
+// phase 4: answer_embedding gradient from dGt | dGgt.  3 then 4 == 0 bit for bit; under data parallelism the
+// 2 x [H, A] block is summed over ranks between the two, so the [A, da] embedding gradient never crosses the wire.
 static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, void* workspace,
                          size_t workspace_bytes, const float* dscores, const ncx_grads* g, void* stream_, int phase) {
     int rc = check_dims(dp);
@@ -835,7 +838,9 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
     // ---- out layer + last hidden layer's activation ------------------------------------------------
     const float* hL = (const float*)(ws + w.h[d.L - 1]);
     float* dpre = (float*)(ws + w.dpre[0]);
-    const bool do1 = phase != 2, do2 = phase != 1;
+    const bool only_de = phase == 4;                    // phase 4: just the dE GEMM
+    const bool skip_de = phase == 3;
+    const bool do1 = phase != 2 && !only_de, do2 = phase != 1 && !only_de;
     if (!do1) {                                       // phase 2: dpre_1 lives where phase 1 left it
         dpre = (float*)(ws + w.dpre[(d.L - 1) & 1]);
     } else {
@@ -928,10 +933,12 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
             rc = run_gemm(U_DW1AK, a, FORM_NN, u[U_DW1AK].plan, ss ? (float*)(ws + w.slab2) : slab,
                           ss ? w.slab2_bytes : w.slab_bytes, nullptr, ss ? ss->s : s); if (rc) return rc;
         }
-        if (do1) {   // dE[a][j] = sum_n dGt[n][a] W1ak[n][j] + sum_n dGgt[n][a] W1agt[n][j],  dGgt = one-hot(aid)^T dSh
+        if (do1) {   // dGgt = one-hot(aid)^T dSh
             NCX_HIP_TRY(hipMemsetAsync(dagt, 0, (size_t)H * d.A * 4, s));
             hipLaunchKernelGGL(k_scatter_dsh_by_answer, dim3(d.B), dim3(256), 0, s, (const float*)dsh, in->answer_aids, d.B, H, d.A, dagt);
             NCX_HIP_TRY(hipGetLastError());
+        }
+        if ((do1 && !skip_de) || only_de) {   // dE[a][j] = sum_n dGt[n][a] W1ak[n][j] + sum_n dGgt[n][a] W1agt[n][j]
             GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 2; a.M = d.A;
             a.a[0] = x_plain(dgt, d.A, H, d.A);  a.b[0] = x_plain(p->w1 + o.a_other, din, H, d.da); a.klen[0] = H;
             a.a[1] = x_plain(dagt, d.A, H, d.A); a.b[1] = x_plain(p->w1 + o.a_gt, din, H, d.da);    a.klen[1] = H;
@@ -942,6 +949,16 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
     } else if (do1) {
         NCX_HIP_TRY(hipMemsetAsync(g->answer_embedding, 0, (size_t)d.A * d.da * 4, s));
     }
+    return NCX_OK;
+}
+
+int ncx_ws_region(const ncx_dims* dp, int32_t which, size_t* offset, size_t* bytes) {
+    if (check_dims(dp) != NCX_OK) return NCX_E_DIMS;
+    if (!offset || !bytes) return NCX_E_NULL;
+    if (which != NCX_WS_DGT) return NCX_E_FLAGS;
+    const WsLayout w = ws_layout(*dp);
+    *offset = w.dgt;
+    *bytes = (dp->flags & NCX_F_A_EMB) ? (size_t)2 * dp->H * dp->A * 4 : 0;
     return NCX_OK;
 }
 

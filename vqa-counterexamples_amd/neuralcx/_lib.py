@@ -15,7 +15,7 @@ NCX_F_ALL = 15
 
 EXPORTS = ("ncx_input_size", "ncx_workspace_bytes", "ncx_forward", "ncx_loss_rank", "ncx_backward", "ncx_backward_phase",
            "ncx_adam_step", "ncx_version", "ncx_profile_begin", "ncx_profile_end", "ncx_plan_query",
-           "ncx_vqa_workspace_bytes", "ncx_vqa_forward", "ncx_knn_workspace_bytes", "ncx_knn")
+           "ncx_vqa_workspace_bytes", "ncx_vqa_forward", "ncx_knn_workspace_bytes", "ncx_knn", "ncx_ws_region")
 
 
 class NcxDims(C.Structure):
@@ -96,6 +96,8 @@ def lib():
     L.ncx_knn.restype = C.c_int
     L.ncx_knn.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                           C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ncx_ws_region.restype = C.c_int
+    L.ncx_ws_region.argtypes = [C.POINTER(NcxDims), C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.ncx_profile_begin.restype = C.c_int
     L.ncx_profile_begin.argtypes = [C.c_uint32, C.c_int32]
     L.ncx_profile_end.restype = C.c_int

@@ -16,7 +16,7 @@ from typing import Dict, Optional
 import torch
 
 from . import dp, ops
-from ._lib import NCX_F_ALL
+from ._lib import NCX_F_ALL, NCX_F_A_EMB
 
 STATE_NAMES = ("answer_embedding.weight", "linear_1.weight", "linear_1.bias", "linear_2.weight", "linear_2.bias",
                "linear_3.weight", "linear_3.bias", "out.weight", "out.bias")
@@ -123,14 +123,22 @@ class NeuralCXEngine:
         scores = ops.forward(d, batch, self.params.fields(), self._ws)
         r = ops.ranking_loss(scores, gt, scale=1.0 / gb)
         if self.world_size > 1:
-            # answer_embedding is first in the flat buffer: its 19 MB all-reduce (RCCL over xGMI, NCCL's own stream)
-            # runs under the second half of backward; only the linear_1.weight bucket is exposed
+            # The embedding gradient dE = dGt^T.W1ak + dGgt^T.W1agt is linear in the 2 x [H, A] block dGt | dGgt: the
+            # ranks sum THAT block (4 MB at H=256) and each computes the complete dE itself, so the 19 MB [A, da]
+            # gradient never crosses xGMI.  Bucket 2 (linear_1.weight .. out.bias, 14.4 MB) is on the wire while the dE
+            # GEMM runs; only answer_embedding is excluded from it (it is first in the flat buffer).
             n_emb = self.params.offsets["linear_1.weight"]
-            ops.backward(d, batch, self.params.fields(), self._ws, r["dscores"], self.grads.fields(), phase=1)
-            h1 = torch.distributed.all_reduce(self.grads.flat[:n_emb], group=self.pg, async_op=True)
-            ops.backward(d, batch, self.params.fields(), self._ws, r["dscores"], self.grads.fields(), phase=2)
-            h2 = torch.distributed.all_reduce(self.grads.flat[n_emb:], group=self.pg, async_op=True)
-            h1.wait(); h2.wait()
+            f = self.params.fields()
+            ops.backward(d, batch, f, self._ws, r["dscores"], self.grads.fields(), phase=3)
+            if self.flags & NCX_F_A_EMB:
+                h1 = torch.distributed.all_reduce(ops.ws_dgt_view(d, self._ws), group=self.pg, async_op=True)
+                h2 = torch.distributed.all_reduce(self.grads.flat[n_emb:], group=self.pg, async_op=True)
+                h1.wait()
+                ops.backward(d, batch, f, self._ws, r["dscores"], self.grads.fields(), phase=4)
+                h2.wait()
+            else:                                   # a_emb lesion: the embedding gradient is zero everywhere
+                ops.backward(d, batch, f, self._ws, r["dscores"], self.grads.fields(), phase=4)
+                torch.distributed.all_reduce(self.grads.flat[n_emb:], group=self.pg)
         else:
             ops.backward(d, batch, self.params.fields(), self._ws, r["dscores"], self.grads.fields())
         ops.adam_step(self.params.flat, self.grads.flat, self.exp_avg, self.exp_avg_sq, self.step_count, lr=self.lr)

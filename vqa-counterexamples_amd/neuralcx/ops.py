@@ -149,7 +149,7 @@ def forward(d: NcxDims, batch: Batch, params: Dict[str, torch.Tensor], ws: torch
 
 def backward(d: NcxDims, batch: Batch, params: Dict[str, torch.Tensor], ws: torch.Tensor, dscores: torch.Tensor,
              grads: Dict[str, torch.Tensor], phase: int = 0) -> None:
-    """phase 0: whole backward.  phase 1 / 2: first / second half (see ncx_backward_phase) for comm overlap."""
+    """phase 0: whole backward.  phases 1 | 2 and 3 | 4: the two ways to halve it for comm overlap (ncx_backward_phase)."""
     p, n = _ws_ptr(ws)
     ins, ps, gs = batch.c_struct(), _params_struct(params, NcxParams), _params_struct(grads, NcxGrads)
     if phase == 0:
@@ -159,6 +159,15 @@ def backward(d: NcxDims, batch: Batch, params: Dict[str, torch.Tensor], ws: torc
         _lib.check(_lib.lib().ncx_backward_phase(C.byref(d), C.byref(ins), C.byref(ps), p, n,
                                                  _ptr(dscores, torch.float32, "dscores"), C.byref(gs), int(phase), _stream()),
                    "ncx_backward_phase")
+
+
+def ws_dgt_view(d: NcxDims, ws: torch.Tensor) -> torch.Tensor:
+    """fp32 view of the workspace block dGt | dGgt (2 x [H, A]) that phase 3 of backward leaves and phase 4 consumes:
+    the bucket a data-parallel job sums over ranks instead of the [A, da] embedding gradient."""
+    off, nbytes = C.c_size_t(0), C.c_size_t(0)
+    _lib.check(_lib.lib().ncx_ws_region(C.byref(d), 1, C.byref(off), C.byref(nbytes)), "ncx_ws_region")
+    base = (ws.data_ptr() + 255) // 256 * 256 - ws.data_ptr()
+    return ws[base + off.value: base + off.value + nbytes.value].view(torch.float32)
 
 
 def ranking_loss(scores: torch.Tensor, gt: torch.Tensor, scale: float = 0.0, want_grad: bool = True):
