@@ -108,6 +108,18 @@ def test_ragged_shapes_vs_oracle(B, K, H, L):
     compare_with_oracle(d, None, params, batch)
 
 
+@pytest.mark.parametrize("S", [2, 3, 4, 8, 16])
+def test_forced_split_k_layouts_vs_oracle(S, monkeypatch):
+    """Aligned split-K with every workgroup layout of WgMap (chunk-per-XCD for S | 8 and 8 | S, incl. padding ids;
+    the interleaved layout otherwise) on the weight-gradient GEMMs, forced through the planner's experiment hooks."""
+    for gid in (0, 1, 4, 6, 7, 9):                       # Gt, Sh, grouped dW1, dE, dW1ak, dW_l
+        monkeypatch.setenv("NCX_SPLIT_%d" % gid, str(S))
+    d = orc.Dims(dv=70, dq=50, dz=18, A=45, H=128, L=2)
+    params = orc.init_params(d, seed=3, gain=3.0)
+    batch = random_case(900 + S, 44, d)                   # M = 1056 rows: 33 k-steps of the row-reduction GEMMs
+    compare_with_oracle(d, None, params, batch)
+
+
 def test_train_mode_explicit_masks_and_generator():
     d = orc.Dims(dv=64, dq=48, dz=16, A=20, H=32, L=3)
     params = orc.init_params(d, seed=5, gain=3.0)

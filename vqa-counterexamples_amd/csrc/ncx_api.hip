@@ -439,7 +439,7 @@ GemmPlan plan_gemm(int form, long long M, long long N, long long ksteps, bool al
 }
 
 // The GEMMs of one step, so that ws_layout and forward/backward agree on split-K slab sizes.
-struct GemmUse { int form; long long M, N, ksteps; bool allow96; GemmPlan plan; long long slab_elems; long long tiles; };
+struct GemmUse { int form; long long M, N, ksteps; bool allow96; GemmPlan plan; long long slab_elems; long long tiles; long long wgs; };
 enum { U_GT = 0, U_SH, U_MAIN, U_FWD_L, U_DW1C, U_DW1S, U_DE, U_DW1AK, U_DAGT, U_DWL, U_DXL, U_COUNT };
 
 static inline long long ks(long long k) { return cdiv(k, GEMM_BK); }
@@ -501,18 +501,31 @@ static void list_uses(const ncx_dims& d, GemmUse* u) {
         long long tiles = cdiv(u[i].M, bm) * cdiv(u[i].N, bn);
         if (grouped) tiles = grouped_tiles(bm, bn);
         u[i].tiles = tiles;
-        u[i].slab_elems = u[i].plan.split > 1 ? tiles * u[i].plan.split * bm * bn : 0;
+        // slab slots = workgroup ids (the chunk-per-XCD layout of WgMap pads some problems)
+        const int S = u[i].plan.split > 1 ? u[i].plan.split : 1;
+        long long wgs = 0;
+        if (grouped) {
+            const long long* sg = i == U_DW1C ? segs_c : segs_s;
+            for (int q = 0; q < 5; ++q)
+                if (sg[q] > 0) wgs += WgMap{(int)cdiv(H, bm), (int)cdiv(sg[q], bn), S}.count();
+        } else {
+            wgs = WgMap{(int)cdiv(u[i].M, bm), (int)cdiv(u[i].N, bn), S}.count();
+        }
+        u[i].wgs = wgs;
+        u[i].slab_elems = S > 1 ? wgs * bm * bn : 0;
     }
     // DW1S rides in DW1C's launch (same tile config): its workgroups' slab slots follow DW1C's
     u[U_DW1S].plan.cfg = u[U_DW1C].plan.cfg;
     {
         int bm, bn; cfg_tile(u[U_DW1C].plan.cfg, bm, bn);
-        u[U_DW1S].tiles = 0;
+        const long long segs_s[4] = {d.dv, d.dq, d.dz, d.da};
+        const int S = u[U_DW1S].plan.split > 1 ? u[U_DW1S].plan.split : 1;
+        u[U_DW1S].tiles = 0; u[U_DW1S].wgs = 0;
         for (int q = 0; q < 4; ++q) {
-            const long long segs_s[4] = {d.dv, d.dq, d.dz, d.da};
             u[U_DW1S].tiles += cdiv(H, bm) * cdiv(segs_s[q], bn);
+            u[U_DW1S].wgs += WgMap{(int)cdiv(H, bm), (int)cdiv(segs_s[q], bn), S}.count();
         }
-        u[U_DW1C].slab_elems = (u[U_DW1C].tiles * u[U_DW1C].plan.split + u[U_DW1S].tiles * u[U_DW1S].plan.split) * bm * bn;
+        u[U_DW1C].slab_elems = (u[U_DW1C].wgs + u[U_DW1S].wgs) * bm * bn;
         u[U_DW1S].slab_elems = 0;
     }
 }
@@ -1001,7 +1014,7 @@ static VqaLayout vqa_layout(const ncx_dims& d, const ncx_mutan_params& m, GemmPl
         }
         if (i == 3) { plans[i].cfg = CFG_64x64; plans[i].split = 1; }
         int bm, bn; cfg_tile(plans[i].cfg, bm, bn);
-        const long long e = plans[i].split > 1 ? cdiv(shp[i][0], bm) * cdiv(shp[i][1], bn) * plans[i].split * bm * bn : 0;
+        const long long e = plans[i].split > 1 ? (long long)WgMap{(int)cdiv(shp[i][0], bm), (int)cdiv(shp[i][1], bn), plans[i].split}.count() * bm * bn : 0;
         if (e > slab) slab = e;
     }
     w.slab_bytes = (size_t)slab * 4;
