@@ -25,6 +25,7 @@ for _p in (ROOT, os.path.join(ROOT, "vqa-counterexamples_amd")):
 import torch
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # same table, "Peak BF16/FP16 MFMA" (dense)
 
 
 def usable_cores():
@@ -88,6 +89,7 @@ def main():
     ap.add_argument("--n_img", type=int, default=82783)
     ap.add_argument("--pool", type=int, default=4, help="distinct resident batches cycled through")
     ap.add_argument("--c3", action="store_true", help="configs[2]: z / answer logits produced per step by the fused HIP MUTAN (ncx_vqa_forward)")
+    ap.add_argument("--bf16", action="store_true", help="configs[4] variant: bf16 MFMA operands for the two dominant GEMMs (NOT the headline: fp32 is)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -118,7 +120,7 @@ def main():
     from neuralcx.engine import NeuralCXEngine
     from neuralcx.synth import SyntheticCX
 
-    eng = NeuralCXEngine(K=args.K, H=args.H, L=args.L, drop_p=0.25, lr=1e-4, device=dev, world_size=world)
+    eng = NeuralCXEngine(K=args.K, H=args.H, L=args.L, drop_p=0.25, lr=1e-4, device=dev, world_size=world, bf16=args.bf16)
     eng.init_parameters(seed=42)                      # identical replicas on every rank
     data = SyntheticCX(n_triplets=args.batch * args.pool * world, K=args.K, n_img=args.n_img, seed=1234, device=dev)
     pool = []
@@ -183,6 +185,13 @@ def main():
         names = {"MAIN": "seg_gemm NT %s (linear_1 candidate segments, fwd)" % plans["MAIN"]["tile"],
                  "DW1C": "seg_gemm TN %s grouped, %d-way aligned split-K (all linear_1 weight-grad columns + dGt, incl. fix-up)"
                          % (plans["DW1C"]["tile"], plans["DW1C"]["ksplit"])}
+        peak = PEAK_F32_MFMA_TFLOPS
+        if args.bf16:
+            peak = PEAK_BF16_MFMA_TFLOPS
+            names = {"MAIN": "gemm_bf16_nt 128x128 (packed candidate rows . packed weights^T, fwd; weight pack excluded)",
+                     "DW1C": "gemm_bf16_tn 128x128, 8 k-chunks (one per XCD) + dpre cast + reduce/scatter (all candidate weight-grad columns + dGt)"}
+            for k in plans:
+                plans[k] = dict(plans[k], tile="128x128", ksplit=1 if k == "MAIN" else 8)
         per = {k: sum(v) / len(v) for k, v in prof.items() if v}
         dom = max(per, key=per.get) if per else None
         roof = None
@@ -194,15 +203,16 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
             if os.path.exists(tpath) and (args.batch, c["K"], c["H"], c["L"]) == (512, 24, 256, 1):
                 traffic = json.load(open(tpath)).get(dom, {}).get("bytes_per_launch")
-            roof = dict(bound="mfma", kernel=names[dom], achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS,
-                        unit="TFLOP/s", frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
+            roof = dict(bound="mfma", kernel=names[dom], achieved=round(ach, 2), peak=peak,
+                        unit="TFLOP/s", frac=round(ach / peak, 4), traffic=None if args.bf16 else traffic,
                         launch_ms=round(per[dom], 4), algorithmic_gflop_per_launch=round(flops[dom] / 1e9, 3),
                         other={k: dict(launch_ms=round(v, 4), tflops=round(flops[k] / (v * 1e-3) / 1e12, 2),
                                        plan=plans[k]) for k, v in per.items()})
         out = dict(metric="VQA-CX triplets/sec (24 candidates each), NeuralCX training step",
                    value=round(gb * args.steps / dt, 1), unit="triplets/s", n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True,
-                   scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                   scaling="weak", vs_baseline=None, dtype="bf16 operands / f32 accumulate (first-layer GEMMs), f32 elsewhere" if args.bf16 else "f32",
+                   data="synthetic",
                    config=dict(workload=("configs[2]: fused HIP MUTAN producer (vqa_forward) + " if args.c3 else "configs[1]: ") +
                                         "NeuralCX MLP train step (fwd+listwise loss/recall+bwd+Adam), synthetic "
                                         "2048-d feats, %d candidates, batch %d per GPU, H=%d, L=%d, dropout 0.25, fp32"

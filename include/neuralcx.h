@@ -43,6 +43,11 @@ extern "C" {
 #define NCX_F_V_RANK   (1u << 2)   /* one-hot candidate rank (cx.py:303-305), else inputs->v_rank   */
 #define NCX_F_A_EMB    (1u << 3)   /* answer embeddings (cx.py:279-282), else noise blocks          */
 #define NCX_F_ALL      (NCX_F_V_MULT | NCX_F_V_DIST | NCX_F_V_RANK | NCX_F_A_EMB)
+/* BASELINE configs[4] ("bf16 weights"; net-new, the reference is fp32 only): the two dominant GEMMs -- candidate
+ * segments of linear_1 forward, and their weight gradient -- take bf16 operands (round-to-nearest-even copies of
+ * the fp32 master weights, inputs and pre-activation gradients) with fp32 accumulation on the bf16 MFMA path;
+ * everything else, including Adam on the fp32 master weights, is unchanged.  Needs NCX_F_ALL (no lesions). */
+#define NCX_F_BF16     (1u << 4)
 /* (v_emb / q_emb / z_emb lesions replace INPUTS by uniform noise: the host does that before the call) */
 
 typedef struct ncx_dims {

@@ -175,6 +175,70 @@ def forward_faithful(params: Dict[str, torch.Tensor], d: Dims,
 
 
 # --------------------------------------------------------------------------------------
+# BASELINE configs[4]: "bf16 weights" variant (net-new: the reference computes in fp32 only)
+# --------------------------------------------------------------------------------------
+def _bf(x: torch.Tensor) -> torch.Tensor:
+    return x.bfloat16().float()          # round to nearest even, as v_cvt_pk_bf16_f32
+
+
+class _Bf16Product(torch.autograd.Function):
+    """y = bf16(x) . bf16(w)^T with fp32 accumulation; grad_w = bf16(g)^T . bf16(x) (what the bf16 MFMA path
+    computes: products of bf16 values are exact in fp32, so only the summation order differs); x needs no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        xb = _bf(x)
+        ctx.save_for_backward(xb)
+        return xb @ _bf(w).t()
+
+    @staticmethod
+    def backward(ctx, g):
+        (xb,) = ctx.saved_tensors
+        return None, _bf(g).t() @ xb
+
+
+def forward_bf16(params: Dict[str, torch.Tensor], d: Dims, image_features, q_emb, z_orig, z_knns, a_knns, answer_aids,
+                 drop_p: float = 0.0, keep_masks: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+    """scores[B,K] of the NCX_F_BF16 variant: the same network as forward_faithful (vqa/models/cx.py:261-333) in its
+    segmented form -- the four per-triplet segments and Gt = W1[:, a_emb_other] . E^T in fp32, the five per-candidate
+    segments [v_k | v_o*v_k | dist, rank | z_k | softmax(a_k)] against [W1 slices | Gt] with BOTH operands rounded to
+    bf16 and fp32 accumulation; hidden layers >= 2, `out`, loss and Adam in fp32."""
+    B, K = image_features.shape[0], d.K
+    W1, b1, E = params["linear_1.weight"], params["linear_1.bias"], params["answer_embedding.weight"]
+    o, c = {}, 0
+    for name, n in (("v_orig", d.dv), ("v_other", d.dv), ("v_mult", d.dv), ("v_dist", 1), ("v_rank", K), ("q_emb", d.dq),
+                    ("z_orig", d.dz), ("z_other", d.dz), ("a_gt", d.da), ("a_other", d.da)):      # cx.py:309-320
+        o[name] = (c, c + n); c += n
+    cols = lambda n: W1[:, o[n][0]:o[n][1]]
+    v_o, v_k = image_features[:, 0], image_features[:, 1:]
+    shared = torch.cat((v_o, q_emb, z_orig, F.embedding(answer_aids, E)), 1) @ \
+        torch.cat((cols("v_orig"), cols("q_emb"), cols("z_orig"), cols("a_gt")), 1).t() + b1
+    gt_mat = cols("a_other") @ E.t()                                                        # [H, A]
+    dist = (v_o[:, None, :] - v_k + 1e-6).norm(dim=2, keepdim=True)                         # cx.py:300
+    rank = torch.eye(K).view(1, K, K).expand(B, K, K)                                       # cx.py:304-305
+    xc = torch.cat((v_k, v_o[:, None, :] * v_k, dist, rank, z_knns, F.softmax(a_knns, dim=-1)), 2).reshape(B * K, -1)
+    wc = torch.cat((cols("v_other"), cols("v_mult"), cols("v_dist"), cols("v_rank"), cols("z_other"), gt_mat), 1)
+    h = F.relu(shared.repeat_interleave(K, 0) + _Bf16Product.apply(xc, wc))
+    if keep_masks is not None:
+        h = h * keep_masks[0].view(B * K, d.H) / (1.0 - drop_p)
+    for l in range(2, d.L + 1):
+        h = F.relu(F.linear(h, params[f"linear_{l}.weight"], params[f"linear_{l}.bias"]))
+        if keep_masks is not None:
+            h = h * keep_masks[l - 1].view(B * K, d.H) / (1.0 - drop_p)
+    return F.linear(h, params["out.weight"], params["out.bias"]).view(B, K)
+
+
+def loss_and_grads_bf16(params, d: Dims, batch: dict, drop_p=0.0, keep_masks=None):
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    scores = forward_bf16(leaf, d, batch["image_features"], batch["q_emb"], batch["z_orig"], batch["z_knns"], batch["a_knns"],
+                          batch["answer_aids"], drop_p=drop_p, keep_masks=keep_masks)
+    loss = ranking_loss(scores, batch["gt"])
+    loss.backward()
+    grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaf.items()}
+    return scores.detach(), loss.detach(), grads
+
+
+# --------------------------------------------------------------------------------------
 # the frozen MUTAN producer upstream of the MLP (SURVEY 8 row f1)
 # --------------------------------------------------------------------------------------
 def mutan_vqa_forward(vp: Dict[str, torch.Tensor], image_features: torch.Tensor, q_emb: torch.Tensor, R: int):

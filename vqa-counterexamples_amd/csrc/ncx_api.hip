@@ -10,6 +10,7 @@
 //   h2, h3 (L >= 2), scores = h_L . w_out + b_out                                                     [MFMA/HBM]
 // Backward mirrors it (see ncx_backward).  Nothing here allocates or synchronises.
 #include "ncx_internal.h"
+#include "ncx_bf16.h"
 #include <stdlib.h>
 #include <stdio.h>
 
@@ -30,10 +31,12 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // One wave per logical row r = b*K + k.  4 rows per 256-thread block.
+__device__ __forceinline__ u16 f32_to_bf16(float x) { return __builtin_bit_cast(u16, (__bf16)x); }     // round to nearest even
+
 __global__ __launch_bounds__(256) void k_prep(ncx_dims d, ncx_inputs in, int* __restrict__ idx_k,
                                               int* __restrict__ idx_o, int* __restrict__ idx_ob,
                                               float* __restrict__ mx, float* __restrict__ inv,
-                                              float* __restrict__ misc) {
+                                              float* __restrict__ misc, u16* __restrict__ xc, Bf16Cols cc) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int M = d.B * d.K;
@@ -79,7 +82,33 @@ __global__ __launch_bounds__(256) void k_prep(ncx_dims d, ncx_inputs in, int* __
         }
         s = wave_sum(s);
         // base-2 log-sum-exp: softmax(a)[c] = exp2(a[c]*log2e - lse2)
-        if (lane == 0) { mx[r] = m * 1.44269504088896341f + __log2f(s); inv[r] = 0.f; }
+        const float lse2 = m * 1.44269504088896341f + __log2f(s);
+        if (lane == 0) { mx[r] = lse2; inv[r] = 0.f; }
+        if (xc) {           // NCX_F_BF16: the softmax row itself, rounded to bf16, is the last segment of the packed row
+            u16* xp = xc + (long long)r * cc.kc + cc.c_p;
+            for (int c = lane * 4; c < d.A; c += 256) {
+                const f32x4 v = load4(a, c, d.A);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < d.A) xp[c + j] = f32_to_bf16(__builtin_amdgcn_exp2f(__builtin_fmaf(v[j], 1.44269504088896341f, -lse2)));
+            }
+        }
+    }
+    if (xc) {               // NCX_F_BF16: [ v_k | v_o * v_k | dist, rank | z_k | (softmax above) | zero padding ]
+        u16* xr = xc + (long long)r * cc.kc;
+        const float* vo = in.feats + (long long)io * d.dv;
+        const float* vk = in.feats + (long long)ik * d.dv;
+        for (int c = lane * 4; c < d.dv; c += 256) {
+            const f32x4 a = load4(vo, c, d.dv), e = load4(vk, c, d.dv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c + j < d.dv) { xr[cc.c_vk + c + j] = f32_to_bf16(e[j]); xr[cc.c_vm + c + j] = f32_to_bf16(a[j] * e[j]); }
+        }
+        if (lane == 0) xr[cc.c_misc] = f32_to_bf16(dist);
+        for (int j = lane; j < d.K; j += 64) xr[cc.c_misc + 1 + j] = f32_to_bf16(j == k ? 1.f : 0.f);
+        const float* zk = in.z_knns + (long long)r * d.dz;
+        for (int c = lane; c < d.dz; c += 64) xr[cc.c_z + c] = f32_to_bf16(zk[c]);
+        for (int c = cc.raw + lane; c < cc.kc; c += 64) xr[c] = 0;
     }
 }
 
@@ -560,6 +589,10 @@ WsLayout ws_layout(const ncx_dims& d) {
         w.slab2_bytes = (size_t)s2 * 4;
         w.slab2 = take(w.slab2_bytes);
     }
+    if (d.flags & NCX_F_BF16) {                          // packed bf16 operands of the two dominant GEMMs (ncx_bf16.h)
+        w.xc = take(bf16_xc_bytes(d)); w.wc = take(bf16_wc_bytes(d));
+        w.dpre_bf = take(bf16_dpre_bytes(d)); w.bf_slab = take(bf16_slab_bytes(d));
+    }
     w.total = off;
     return w;
 }
@@ -607,6 +640,7 @@ static int check_dims(const ncx_dims* d) {
     if ((long long)d->B * d->K > (1ll << 30) / 4 || d->B > NCX_SCATTER_MAX_B) return NCX_E_DIMS;
     if (d->dv < 4 || d->dq < 4 || d->dz < 4 || d->da < 4 || d->A < 4 || d->H < 4 || d->K < 3) return NCX_E_DIMS;   // 16-byte windows
     if (d->drop_p < 0.f || d->drop_p >= 1.f) return NCX_E_DIMS;
+    if ((d->flags & NCX_F_BF16) && (d->flags & NCX_F_ALL) != NCX_F_ALL) return NCX_E_FLAGS;    // bf16 variant: no lesions
     return NCX_OK;
 }
 
@@ -619,6 +653,18 @@ static ProfState g_prof = {false, 0u, 0, 0, nullptr, nullptr};
 
 static int run_gemm_impl(GemmArgs& a, int form, const GemmPlan& pl, float* slab, size_t slab_bytes,
                          const float* reduce_bias, hipStream_t s);
+
+// HIP-event bracket of a launch sequence that is not a run_gemm call (the bf16 variant's GEMMs)
+static int prof_open(int use_id, hipStream_t s) {
+    if (g_prof.on && ((g_prof.mask >> use_id) & 1u) && g_prof.n < g_prof.cap) NCX_HIP_TRY(hipEventRecord(g_prof.ev[2 * g_prof.n], s));
+    return NCX_OK;
+}
+static int prof_close(int use_id, hipStream_t s) {
+    if (g_prof.on && ((g_prof.mask >> use_id) & 1u) && g_prof.n < g_prof.cap) {
+        NCX_HIP_TRY(hipEventRecord(g_prof.ev[2 * g_prof.n + 1], s)); g_prof.ids[g_prof.n] = use_id; ++g_prof.n;
+    }
+    return NCX_OK;
+}
 
 // GEMM driver: runs `a` with plan `pl`; when split, redirects the outputs to slabs and reduces them.
 static int run_gemm(int use_id, GemmArgs& a, int form, const GemmPlan& pl, float* slab, size_t slab_bytes,
@@ -712,7 +758,10 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
     float* slab_side = ss ? (float*)(ws + w.slab2) : slab;
     const size_t slab_side_bytes = ss ? w.slab2_bytes : w.slab_bytes;
     if (ss) { rc = side_fork(ss, s); if (rc) return rc; }
-    hipLaunchKernelGGL(k_prep, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, s, d, *in, idx_k, idx_o, idx_ob, mx, inv, misc);
+    const bool bf16 = d.flags & NCX_F_BF16;
+    u16* xc = bf16 ? (u16*)(ws + w.xc) : nullptr;
+    hipLaunchKernelGGL(k_prep, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, s, d, *in, idx_k, idx_o, idx_ob, mx, inv, misc, xc,
+                       bf16_cols(d));
     NCX_HIP_TRY(hipGetLastError());
 
     // Gt[H, A] = W1[:, a_other] . E^T
@@ -741,7 +790,15 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
         if (ss) { rc = side_join(ss, s); if (rc) return rc; }
     }
     // h1 = drop(relu(Sh[b] + candidate segments))
-    {
+    if (bf16) {     // plain bf16 product of the packed rows with the packed weights (Wc repacked every step: weights move)
+        rc = bf16_pack_wc(d, p->w1, gt, (u16*)(ws + w.wc), s); if (rc) return rc;
+        EpiArgs e{};
+        e.rowadd = sh; e.ld_rowadd = H; e.rowdiv = d.K;
+        set_dropout(e, d, *in, 1, M);
+        rc = prof_open(U_MAIN, s); if (rc) return rc;
+        rc = bf16_main_forward(d, xc, (const u16*)(ws + w.wc), e, (float*)(ws + w.h[0]), s); if (rc) return rc;
+        rc = prof_close(U_MAIN, s); if (rc) return rc;
+    } else {
         GemmArgs a{}; a.mode = MODE_CHAIN; a.M = M;
         int n = 0;
         a.a[n] = x_gather(in->feats, d.dv, idx_k, M, d.dv); a.b[n] = x_plain(p->w1 + o.v_other, din, H, d.dv); a.klen[n] = d.dv; ++n;
@@ -911,8 +968,15 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
             a.a[n] = x_plain(dsh, H, d.B, H); a.b[n] = x; a.klen[n] = d.B; a.out[n] = out; a.ldo[n] = din; a.n_cols[n] = x.cols;
             a.split[n] = u[U_DW1S].plan.split; ++n; };
         // the dGt problem is what the answer_embedding gradient waits for: phase 1 launches it alone
-        const bool want_dgt = aemb && do1, want_rest = do2;
-        if (want_rest) {
+        const bool bf16 = d.flags & NCX_F_BF16;
+        const bool want_dgt = aemb && do1 && !bf16, want_rest = do2;
+        if (bf16 && do1) {   // all candidate columns + dGt: dpre^T . Xc on the bf16 MFMA path (complete in phases 0, 1, 3)
+            rc = prof_open(U_DW1C, s); if (rc) return rc;
+            rc = bf16_dw1c(d, dpre, (u16*)(ws + w.dpre_bf), (const u16*)(ws + w.xc), (float*)(ws + w.bf_slab), g->w1, dgt, s);
+            if (rc) return rc;
+            rc = prof_close(U_DW1C, s); if (rc) return rc;
+        }
+        if (want_rest && !bf16) {
             add_c(x_gather(in->feats, d.dv, idx_k, M, d.dv), g->w1 + o.v_other, din);
             if (d.flags & NCX_F_V_MULT) add_c(x_gather_mul(in->feats, d.dv, idx_k, idx_o, M, d.dv), g->w1 + o.v_mult, din);
             add_c(x_plain(misc, d.K + 1, M, d.K + 1), g->w1 + o.v_dist, din);

@@ -1,0 +1,325 @@
+// ncx_bf16.hip -- bf16-operand GEMMs of the NCX_F_BF16 variant (see ncx_bf16.h).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ncx_bf16.h"
+#include "ncx_internal.h"
+
+namespace ncx {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ u16 to_bf16(float x) { return __builtin_bit_cast(u16, (__bf16)x); }   // RNE (v_cvt_pk_bf16_f32)
+
+// ---- weight pack: Wc[h][c] ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_wc(ncx_dims d, Bf16Cols cc, SegOffsets o, const float* __restrict__ w1,
+                                                 const float* __restrict__ gt, u16* __restrict__ wc, int Hp) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)Hp * cc.kc) return;
+    const int h = (int)(i / cc.kc), c = (int)(i - (long long)h * cc.kc);
+    float v = 0.f;
+    if (h < d.H && c < cc.raw) {
+        const float* row = w1 + (long long)h * o.din;
+        if (c < cc.c_vm) v = row[o.v_other + c];
+        else if (c < cc.c_misc) v = row[o.v_mult + (c - cc.c_vm)];
+        else if (c < cc.c_z) v = row[o.v_dist + (c - cc.c_misc)];          // v_dist column followed by the K v_rank columns
+        else if (c < cc.c_p) v = row[o.z_other + (c - cc.c_z)];
+        else v = gt[(long long)h * d.A + (c - cc.c_p)];
+    }
+    wc[i] = to_bf16(v);
+}
+
+__global__ __launch_bounds__(256) void k_dpre_to_bf16(const float* __restrict__ x, int M, int H, int Hp, u16* __restrict__ y) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)M * Hp) return;
+    const int r = (int)(i / Hp), c = (int)(i - (long long)r * Hp);
+    y[i] = to_bf16(c < H ? x[(long long)r * H + c] : 0.f);
+}
+
+// ---- NT: C[M, N] = A[M, Kc] . B[N, Kc]^T, both row-major bf16 (reduction along the contiguous dimension) ---------
+// 256 threads = 2 x 2 waves, wave tile (BM/2) x (BN/2) in 16x16 blocks, K-step 64 (two v_mfma_f32_16x16x32_bf16 per
+// block), register-staged double-buffered LDS with TWO K-steps of global loads in flight per workgroup (the product
+// is bound by operand delivery, not by the MFMA pipe).  LDS rows are padded to 144 B: ds_read_b128 conflict-free.
+constexpr int NT_PITCH = 144;                 // bytes per LDS row: 64 bf16 + 16 B pad
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const u16* __restrict__ A, int M, const u16* __restrict__ B, int N,
+                                                              int Kc, float* __restrict__ out, long long ldo, const EpiArgs epi) {
+    constexpr int NA = BM / 32, NB = BN / 32, WM = BM / 32, WN = BN / 32;
+    constexpr int A_BYTES = BM * NT_PITCH, B_BYTES = BN * NT_PITCH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_bf16[];
+    unsigned char* const lds_a = smem_bf16;                    // [2][A_BYTES]
+    unsigned char* const lds_b = smem_bf16 + 2 * A_BYTES;      // [2][B_BYTES]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+    const WgMap wmap{(M + BM - 1) / BM, (N + BN - 1) / BN, 1};
+    int tm, tn, z;
+    wmap.decode(blockIdx.x, tm, tn, z);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int lr = tid >> 3, lc = tid & 7;                     // loader: row within a 32-row slab, 16-byte chunk of the 128-byte k-window
+    const u16* pa[NA];
+    const u16* pb[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) pa[i] = A + (long long)min(m0 + lr + 32 * i, M - 1) * Kc + 8 * lc;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) pb[i] = B + (long long)min(n0 + lr + 32 * i, N - 1) * Kc + 8 * lc;
+
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
+    auto issue = [&](u32x4 (&ra)[NA], u32x4 (&rb)[NB], int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) ra[i] = *(const u32x4*)(pa[i] + (long long)kt * 64);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) rb[i] = *(const u32x4*)(pb[i] + (long long)kt * 64);
+    };
+    auto stash = [&](const u32x4 (&ra)[NA], const u32x4 (&rb)[NB], int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *(u32x4*)(lds_a + buf * A_BYTES + (lr + 32 * i) * NT_PITCH + lc * 16) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *(u32x4*)(lds_b + buf * B_BYTES + (lr + 32 * i) * NT_PITCH + lc * 16) = rb[i];
+    };
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const unsigned char* ta = lds_a + buf * A_BYTES + (wm0 + li) * NT_PITCH + lk * 16;
+        const unsigned char* tb = lds_b + buf * B_BYTES + (wn0 + li) * NT_PITCH + lk * 16;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[WM], bf[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) af[i] = *(const bf16x8*)(ta + i * 16 * NT_PITCH + s * 64);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bf[j] = *(const bf16x8*)(tb + j * 16 * NT_PITCH + s * 64);
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int nk = Kc / 64;
+    issue(ra0, rb0, 0);
+    if (nk > 1) issue(ra1, rb1, 1);
+    stash(ra0, rb0, 0);
+    __syncthreads();
+    for (int t = 0; t < nk; t += 2) {
+        if (t + 2 < nk) issue(ra0, rb0, t + 2);
+        compute(0);
+        if (t + 1 < nk) stash(ra1, rb1, 1);
+        __syncthreads();
+        if (t + 1 >= nk) break;
+        if (t + 3 < nk) issue(ra1, rb1, t + 3);
+        compute(1);
+        if (t + 2 < nk) stash(ra0, rb0, 0);
+        __syncthreads();
+    }
+    // row-block loop kept rolled (compile-time-indexed selects pick the block's accumulators): fully unrolled, the 64
+    // inlined epilogues exceed the unroller's size limit and the accumulator array ends up in scratch
+#pragma unroll 1
+    for (int i = 0; i < WM; ++i) {
+        f32x4 row[WN];
+#pragma unroll
+        for (int ii = 0; ii < WM; ++ii)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                if (ii == 0) row[j] = acc[0][j];
+                else row[j] = (ii == i) ? acc[ii][j] : row[j];
+            }
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = m0 + wm0 + 16 * i + 4 * lk + q, n = n0 + wn0 + 16 * j + li;
+                if (r < M && n < N) out[(long long)r * ldo + n] = apply_epilogue(epi, row[j][q], r, n, N);
+            }
+    }
+}
+
+// ---- TN: C[Hm, Kc] (+)= sum over rows k of A[k][m] . B[k][n], both row-major bf16 with the reduction along ROWS --------
+// The LDS image keeps the global layout ([64 k-rows][128 columns], rows padded to 288 B) and ds_read_b64_tr_b16 delivers
+// the MFMA operands transposed: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4 x 16 block and
+// receives column (lane & 15) of the 4 rows.  Group g takes rows 4g..4g+3 and 16+4g..16+4g+3 of each 32-row sub-step
+// for BOTH operands (same k order on both sides; the two blocks of a 32-lane half fall on disjoint banks).
+// Workgroup id -> k-chunk z = id % 8 (one chunk per XCD: its slice of A stays in that L2), tile = id / 8, m-tiles adjacent.
+constexpr int TN_PITCH = 288;
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const u16* __restrict__ A, int lda, const u16* __restrict__ B, int ldb,
+                                                              int rows, int chunk_rows, int tiles_m, float* __restrict__ slab,
+                                                              int H, int Kc) {
+    constexpr int WM = BM / 32, WN = BN / 32;
+    constexpr int A_BYTES = 64 * TN_PITCH, B_BYTES = 64 * TN_PITCH;
+    static_assert(BM == 128 && BN == 128, "loader mapping assumes 128-column tiles");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_bf16[];
+    unsigned char* const lds_a = smem_bf16;
+    unsigned char* const lds_b = smem_bf16 + 2 * A_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
+    const int z = blockIdx.x & 7, t = blockIdx.x >> 3;
+    const int tm = t % tiles_m, tn = t / tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int k0 = z * chunk_rows, k1 = min(k0 + chunk_rows, rows);
+    if (k0 >= rows) return;                                      // empty chunk (uniform per workgroup)
+    const int lr = tid >> 4, lc = tid & 15;                      // loader: row within a 16-row slab, 16-byte chunk of the 256-byte row
+    const u16* pa = A + m0 + 8 * lc;
+    const u16* pb = B + n0 + 8 * lc;
+
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
+    auto issue = [&](u32x4 (&ra)[4], u32x4 (&rb)[4], int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + kt * 64 + lr + 16 * i, kc = min(k, rows - 1);
+            ra[i] = *(const u32x4*)(pa + (long long)kc * lda);
+            rb[i] = *(const u32x4*)(pb + (long long)kc * ldb);
+            if (k >= k1) { ra[i] = u32x4{0u, 0u, 0u, 0u}; rb[i] = u32x4{0u, 0u, 0u, 0u}; }
+        }
+    };
+    auto stash = [&](const u32x4 (&ra)[4], const u32x4 (&rb)[4], int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(u32x4*)(lds_a + buf * A_BYTES + (lr + 16 * i) * TN_PITCH + lc * 16) = ra[i];
+            *(u32x4*)(lds_b + buf * B_BYTES + (lr + 16 * i) * TN_PITCH + lc * 16) = rb[i];
+        }
+    };
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+    const int tq = li >> 2, tp = li & 3;                          // transposed-read role of this lane inside its 16-lane group
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const unsigned char* ta = lds_a + buf * A_BYTES + (4 * lk + tq) * TN_PITCH + (wm0 + 4 * tp) * 2;
+        const unsigned char* tb = lds_b + buf * B_BYTES + (4 * lk + tq) * TN_PITCH + (wn0 + 4 * tp) * 2;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[WM], bf[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                const unsigned char* p = ta + s * 32 * TN_PITCH + i * 32;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 16 * TN_PITCH));
+                af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const unsigned char* p = tb + s * 32 * TN_PITCH + j * 32;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 16 * TN_PITCH));
+                bf[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int nk = (k1 - k0 + 63) / 64;
+    issue(ra0, rb0, 0);
+    if (nk > 1) issue(ra1, rb1, 1);
+    stash(ra0, rb0, 0);
+    __syncthreads();
+    for (int t2 = 0; t2 < nk; t2 += 2) {
+        if (t2 + 2 < nk) issue(ra0, rb0, t2 + 2);
+        compute(0);
+        if (t2 + 1 < nk) stash(ra1, rb1, 1);
+        __syncthreads();
+        if (t2 + 1 >= nk) break;
+        if (t2 + 3 < nk) issue(ra1, rb1, t2 + 3);
+        compute(1);
+        if (t2 + 2 < nk) stash(ra0, rb0, 0);
+        __syncthreads();
+    }
+    float* dst = slab + (long long)z * H * Kc;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = m0 + wm0 + 16 * i + 4 * lk + q;
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int n = n0 + wn0 + 16 * j + li;
+                if (m < H && n < Kc) dst[(long long)m * Kc + n] = acc[i][j][q];
+            }
+        }
+}
+
+// dWc[h][c] = sum of the non-empty k-chunk slabs in fixed order, scattered to d linear_1.weight / dGt
+__global__ __launch_bounds__(256) void k_bf16_reduce_dwc(ncx_dims d, Bf16Cols cc, SegOffsets o, const float* __restrict__ slab, int nz,
+                                                         float* __restrict__ g_w1, float* __restrict__ dgt) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)d.H * cc.raw) return;
+    const int h = (int)(i / cc.raw), c = (int)(i - (long long)h * cc.raw);
+    float v = 0.f;
+    for (int z = 0; z < nz; ++z) v += slab[((long long)z * d.H + h) * cc.kc + c];
+    float* row = g_w1 + (long long)h * o.din;
+    if (c < cc.c_vm) row[o.v_other + c] = v;
+    else if (c < cc.c_misc) row[o.v_mult + (c - cc.c_vm)] = v;
+    else if (c < cc.c_z) row[o.v_dist + (c - cc.c_misc)] = v;
+    else if (c < cc.c_p) row[o.z_other + (c - cc.c_z)] = v;
+    else dgt[(long long)h * d.A + (c - cc.c_p)] = v;
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------
+int bf16_pack_wc(const ncx_dims& d, const float* w1, const float* gt, u16* wc, hipStream_t s) {
+    const Bf16Cols cc = bf16_cols(d);
+    const int Hp = (d.H + 127) / 128 * 128;
+    const long long n = (long long)Hp * cc.kc;
+    hipLaunchKernelGGL(k_pack_wc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, cc, seg_offsets(d), w1, gt, wc, Hp);
+    NCX_HIP_TRY(hipGetLastError());
+    return NCX_OK;
+}
+
+int bf16_main_forward(const ncx_dims& d, const u16* xc, const u16* wc, const EpiArgs& epi, float* h1, hipStream_t s) {
+    const Bf16Cols cc = bf16_cols(d);
+    const int M = d.B * d.K;
+    constexpr int BM = 128, BN = 128;
+    const int lds = 2 * (BM + BN) * NT_PITCH;
+    static bool attr = false;
+    if (!attr) {
+        NCX_HIP_TRY(hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    const int wgs = ((M + BM - 1) / BM) * ((d.H + BN - 1) / BN);
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN>), dim3(wgs), dim3(256), lds, s, xc, M, wc, d.H, cc.kc, h1, (long long)d.H, epi);
+    NCX_HIP_TRY(hipGetLastError());
+    return NCX_OK;
+}
+
+int bf16_dw1c(const ncx_dims& d, const float* dpre, u16* dpre_bf, const u16* xc, float* slab, float* g_w1, float* dgt,
+              hipStream_t s) {
+    const Bf16Cols cc = bf16_cols(d);
+    const int M = d.B * d.K, Hp = (d.H + 127) / 128 * 128;
+    {
+        const long long n = (long long)M * Hp;
+        hipLaunchKernelGGL(k_dpre_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dpre, M, d.H, Hp, dpre_bf);
+        NCX_HIP_TRY(hipGetLastError());
+    }
+    constexpr int BM = 128, BN = 128;
+    const int lds = 4 * 64 * TN_PITCH;
+    static bool attr = false;
+    if (!attr) {
+        NCX_HIP_TRY(hipFuncSetAttribute((const void*)gemm_bf16_tn_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    const int chunk = (int)(((long long)(M + BF16_SPLIT - 1) / BF16_SPLIT + 63) / 64 * 64);
+    const int nz = (M + chunk - 1) / chunk;
+    const int tiles_m = Hp / BM, tiles_n = cc.kc / BN;
+    hipLaunchKernelGGL((gemm_bf16_tn_kernel<BM, BN>), dim3(tiles_m * tiles_n * BF16_SPLIT), dim3(256), lds, s, (const u16*)dpre_bf, Hp,
+                       xc, cc.kc, M, chunk, tiles_m, slab, d.H, cc.kc);
+    NCX_HIP_TRY(hipGetLastError());
+    const long long n = (long long)d.H * cc.raw;
+    hipLaunchKernelGGL(k_bf16_reduce_dwc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, cc, seg_offsets(d), (const float*)slab, nz,
+                       g_w1, dgt);
+    NCX_HIP_TRY(hipGetLastError());
+    return NCX_OK;
+}
+
+}  // namespace ncx

@@ -57,6 +57,7 @@ struct WsLayout {
     size_t slab;                        // split-K slabs (max over all uses)
     size_t slab_bytes;
     size_t slab2, slab2_bytes;          // slab of the GEMMs that run on the internal side stream
+    size_t xc, wc, dpre_bf, bf_slab;    // NCX_F_BF16: packed bf16 candidate rows / weights / dpre, k-chunk slabs of dWc
     size_t total;
 };
 constexpr int NCX_COLSUM_CHUNKS = 256;
