@@ -188,10 +188,10 @@ def main():
         peak = PEAK_F32_MFMA_TFLOPS
         if args.bf16:
             peak = PEAK_BF16_MFMA_TFLOPS
-            names = {"MAIN": "gemm_bf16_nt 128x128 (packed candidate rows . packed weights^T, fwd; weight pack excluded)",
+            names = {"MAIN": "gemm_bf16_nt (packed candidate rows . packed weights^T, fwd; 64x64 or 128x128 tiles by workgroup count; weight pack excluded)",
                      "DW1C": "gemm_bf16_tn 128x128, 8 k-chunks (one per XCD) + dpre cast + reduce/scatter (all candidate weight-grad columns + dGt)"}
             for k in plans:
-                plans[k] = dict(plans[k], tile="128x128", ksplit=1 if k == "MAIN" else 8)
+                plans[k] = dict(plans[k], tile="bf16", ksplit=1 if k == "MAIN" else 8)
         per = {k: sum(v) / len(v) for k, v in prof.items() if v}
         dom = max(per, key=per.get) if per else None
         roof = None

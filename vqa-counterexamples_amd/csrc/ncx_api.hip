@@ -32,6 +32,12 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // One wave per logical row r = b*K + k.  4 rows per 256-thread block.
 __device__ __forceinline__ u16 f32_to_bf16(float x) { return __builtin_bit_cast(u16, (__bf16)x); }     // round to nearest even
+// 4 consecutive bf16 at an 8-byte aligned position (one store); `valid` < 4 keeps the tail of a segment untouched
+__device__ __forceinline__ void store_bf16x4(u16* p, const float (&v)[4], int valid) {
+    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+    if (valid >= 4) { *(u16x4*)p = u16x4{f32_to_bf16(v[0]), f32_to_bf16(v[1]), f32_to_bf16(v[2]), f32_to_bf16(v[3])}; }
+    else { for (int j = 0; j < valid; ++j) p[j] = f32_to_bf16(v[j]); }
+}
 
 __global__ __launch_bounds__(256) void k_prep(ncx_dims d, ncx_inputs in, int* __restrict__ idx_k,
                                               int* __restrict__ idx_o, int* __restrict__ idx_ob,
@@ -88,26 +94,35 @@ __global__ __launch_bounds__(256) void k_prep(ncx_dims d, ncx_inputs in, int* __
             u16* xp = xc + (long long)r * cc.kc + cc.c_p;
             for (int c = lane * 4; c < d.A; c += 256) {
                 const f32x4 v = load4(a, c, d.A);
+                float e[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (c + j < d.A) xp[c + j] = f32_to_bf16(__builtin_amdgcn_exp2f(__builtin_fmaf(v[j], 1.44269504088896341f, -lse2)));
+                for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[j], 1.44269504088896341f, -lse2));
+                store_bf16x4(xp + c, e, d.A - c);
             }
         }
     }
-    if (xc) {               // NCX_F_BF16: [ v_k | v_o * v_k | dist, rank | z_k | (softmax above) | zero padding ]
+    if (xc) {               // NCX_F_BF16: [ v_k | v_o * v_k | dist, rank | z_k | (softmax above) ], zero in the gaps
         u16* xr = xc + (long long)r * cc.kc;
         const float* vo = in.feats + (long long)io * d.dv;
         const float* vk = in.feats + (long long)ik * d.dv;
-        for (int c = lane * 4; c < d.dv; c += 256) {
-            const f32x4 a = load4(vo, c, d.dv), e = load4(vk, c, d.dv);
+        for (int c = lane * 4; c < cc.c_vm; c += 256) {               // (segments are padded to multiples of 8 columns)
+            const f32x4 a = load4(vo, c, d.dv), e = load4(vk, c, d.dv);   // zero beyond dv
+            float pk[4], pm[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (c + j < d.dv) { xr[cc.c_vk + c + j] = f32_to_bf16(e[j]); xr[cc.c_vm + c + j] = f32_to_bf16(a[j] * e[j]); }
+            for (int j = 0; j < 4; ++j) { pk[j] = e[j]; pm[j] = a[j] * e[j]; }
+            store_bf16x4(xr + cc.c_vk + c, pk, 4);
+            store_bf16x4(xr + cc.c_vm + c, pm, 4);
         }
-        if (lane == 0) xr[cc.c_misc] = f32_to_bf16(dist);
-        for (int j = lane; j < d.K; j += 64) xr[cc.c_misc + 1 + j] = f32_to_bf16(j == k ? 1.f : 0.f);
+        for (int j = lane; j < cc.c_z - cc.c_misc; j += 64)
+            xr[cc.c_misc + j] = f32_to_bf16(j == 0 ? dist : (j <= d.K && j - 1 == k ? 1.f : 0.f));
         const float* zk = in.z_knns + (long long)r * d.dz;
-        for (int c = lane; c < d.dz; c += 64) xr[cc.c_z + c] = f32_to_bf16(zk[c]);
+        for (int c = lane * 4; c < cc.c_p - cc.c_z; c += 256) {
+            float pz[4];
+            const f32x4 z4 = load4(zk, c, d.dz);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pz[j] = z4[j];
+            store_bf16x4(xr + cc.c_z + c, pz, 4);
+        }
         for (int c = cc.raw + lane; c < cc.kc; c += 64) xr[c] = 0;
     }
 }

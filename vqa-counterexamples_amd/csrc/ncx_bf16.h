@@ -17,10 +17,13 @@ namespace ncx {
 
 typedef unsigned short u16;
 
+// Column layout of a packed row; every segment starts on a multiple of 8 columns (16-byte vector stores in k_prep),
+// the gaps are zero in Xc and Wc.
 struct Bf16Cols { int c_vk, c_vm, c_misc, c_z, c_p, raw, kc; };
 static inline Bf16Cols bf16_cols(const ncx_dims& d) {
     Bf16Cols c;
-    c.c_vk = 0; c.c_vm = d.dv; c.c_misc = 2 * d.dv; c.c_z = c.c_misc + d.K + 1; c.c_p = c.c_z + d.dz;
+    auto up8 = [](int x) { return (x + 7) / 8 * 8; };
+    c.c_vk = 0; c.c_vm = up8(d.dv); c.c_misc = c.c_vm + up8(d.dv); c.c_z = c.c_misc + up8(d.K + 1); c.c_p = c.c_z + up8(d.dz);
     c.raw = c.c_p + d.A;
     c.kc = (c.raw + 127) / 128 * 128;          // whole 128-column tiles of the weight-gradient GEMM, 64-deep K-steps of the forward
     return c;

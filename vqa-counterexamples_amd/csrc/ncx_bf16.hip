@@ -22,10 +22,10 @@ __global__ __launch_bounds__(256) void k_pack_wc(ncx_dims d, Bf16Cols cc, SegOff
     float v = 0.f;
     if (h < d.H && c < cc.raw) {
         const float* row = w1 + (long long)h * o.din;
-        if (c < cc.c_vm) v = row[o.v_other + c];
-        else if (c < cc.c_misc) v = row[o.v_mult + (c - cc.c_vm)];
-        else if (c < cc.c_z) v = row[o.v_dist + (c - cc.c_misc)];          // v_dist column followed by the K v_rank columns
-        else if (c < cc.c_p) v = row[o.z_other + (c - cc.c_z)];
+        if (c < cc.c_vm) { if (c < d.dv) v = row[o.v_other + c]; }
+        else if (c < cc.c_misc) { if (c - cc.c_vm < d.dv) v = row[o.v_mult + (c - cc.c_vm)]; }
+        else if (c < cc.c_z) { if (c - cc.c_misc < d.K + 1) v = row[o.v_dist + (c - cc.c_misc)]; }   // v_dist column, then the K v_rank columns
+        else if (c < cc.c_p) { if (c - cc.c_z < d.dz) v = row[o.z_other + (c - cc.c_z)]; }
         else v = gt[(long long)h * d.A + (c - cc.c_p)];
     }
     wc[i] = to_bf16(v);
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_dpre_to_bf16(const float* __restrict__ 
 // is bound by operand delivery, not by the MFMA pipe).  LDS rows are padded to 144 B: ds_read_b128 conflict-free.
 constexpr int NT_PITCH = 144;                 // bytes per LDS row: 64 bf16 + 16 B pad
 template <int BM, int BN>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_nt_kernel(const u16* __restrict__ A, int M, const u16* __restrict__ B, int N,
+__global__ __launch_bounds__(256, (BM * BN <= 64 * 64) ? 4 : (BM * BN <= 64 * 128) ? 3 : 2) void gemm_bf16_nt_kernel(const u16* __restrict__ A, int M, const u16* __restrict__ B, int N,
                                                               int Kc, float* __restrict__ out, long long ldo, const EpiArgs epi) {
     constexpr int NA = BM / 32, NB = BN / 32, WM = BM / 32, WN = BN / 32;
     constexpr int A_BYTES = BM * NT_PITCH, B_BYTES = BN * NT_PITCH;
@@ -260,10 +260,10 @@ __global__ __launch_bounds__(256) void k_bf16_reduce_dwc(ncx_dims d, Bf16Cols cc
     float v = 0.f;
     for (int z = 0; z < nz; ++z) v += slab[((long long)z * d.H + h) * cc.kc + c];
     float* row = g_w1 + (long long)h * o.din;
-    if (c < cc.c_vm) row[o.v_other + c] = v;
-    else if (c < cc.c_misc) row[o.v_mult + (c - cc.c_vm)] = v;
-    else if (c < cc.c_z) row[o.v_dist + (c - cc.c_misc)] = v;
-    else if (c < cc.c_p) row[o.z_other + (c - cc.c_z)] = v;
+    if (c < cc.c_vm) { if (c < d.dv) row[o.v_other + c] = v; }
+    else if (c < cc.c_misc) { if (c - cc.c_vm < d.dv) row[o.v_mult + (c - cc.c_vm)] = v; }
+    else if (c < cc.c_z) { if (c - cc.c_misc < d.K + 1) row[o.v_dist + (c - cc.c_misc)] = v; }
+    else if (c < cc.c_p) { if (c - cc.c_z < d.dz) row[o.z_other + (c - cc.c_z)] = v; }
     else dgt[(long long)h * d.A + (c - cc.c_p)] = v;
 }
 
@@ -277,20 +277,37 @@ int bf16_pack_wc(const ncx_dims& d, const float* w1, const float* gt, u16* wc, h
     return NCX_OK;
 }
 
-int bf16_main_forward(const ncx_dims& d, const u16* xc, const u16* wc, const EpiArgs& epi, float* h1, hipStream_t s) {
-    const Bf16Cols cc = bf16_cols(d);
-    const int M = d.B * d.K;
-    constexpr int BM = 128, BN = 128;
+template <int BM, int BN>
+static int launch_bf16_nt(const u16* xc, int M, const u16* wc, int N, int kc, const EpiArgs& epi, float* out, hipStream_t s) {
     const int lds = 2 * (BM + BN) * NT_PITCH;
     static bool attr = false;
     if (!attr) {
         NCX_HIP_TRY(hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr = true;
     }
-    const int wgs = ((M + BM - 1) / BM) * ((d.H + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN>), dim3(wgs), dim3(256), lds, s, xc, M, wc, d.H, cc.kc, h1, (long long)d.H, epi);
+    const int wgs = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN>), dim3(wgs), dim3(256), lds, s, xc, M, wc, N, kc, out, (long long)N, epi);
     NCX_HIP_TRY(hipGetLastError());
     return NCX_OK;
+}
+
+int bf16_main_forward(const ncx_dims& d, const u16* xc, const u16* wc, const EpiArgs& epi, float* h1, hipStream_t s) {
+    const Bf16Cols cc = bf16_cols(d);
+    const int M = d.B * d.K;
+    // The product is bound by operand delivery (global-load latency x bytes in flight), not by the MFMA pipe: prefer the
+    // tile that puts >= 2 workgroups on every CU.  NCX_BF16_NT_CFG (0..3) overrides for experiments.
+    int cfg = -1;
+    { const char* e = getenv("NCX_BF16_NT_CFG"); if (e) cfg = atoi(e); }
+    if (cfg < 0) {
+        const long long t128 = (long long)((M + 127) / 128) * ((d.H + 127) / 128);
+        cfg = t128 >= 2LL * num_cus() ? 0 : 3;
+    }
+    switch (cfg) {
+    case 0:  return launch_bf16_nt<128, 128>(xc, M, wc, d.H, cc.kc, epi, h1, s);
+    case 1:  return launch_bf16_nt<64, 128>(xc, M, wc, d.H, cc.kc, epi, h1, s);
+    case 2:  return launch_bf16_nt<128, 64>(xc, M, wc, d.H, cc.kc, epi, h1, s);
+    default: return launch_bf16_nt<64, 64>(xc, M, wc, d.H, cc.kc, epi, h1, s);
+    }
 }
 
 int bf16_dw1c(const ncx_dims& d, const float* dpre, u16* dpre_bf, const u16* xc, float* slab, float* g_w1, float* dgt,
