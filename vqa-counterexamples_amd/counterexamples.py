@@ -72,6 +72,7 @@ def build_parser():
     p.add_argument("--syn_val", type=int, default=4096)
     p.add_argument("--syn_images", type=int, default=82783)
     p.add_argument("--max_steps", type=int, default=-1, help="stop an epoch early (smoke runs)")
+    p.add_argument("--bf16", action="store_true", help="bf16 operands on the two dominant GEMMs (fp32 accumulate / master weights)")
     p.add_argument("--path_trainset", type=str, default=None, help="overrides vqa.path_trainset of the YAML")
     p.add_argument("--path_features", type=str, default=None, help="overrides coco.path_features / path_raw of the YAML")
     return p
@@ -105,7 +106,7 @@ class Runner:
                                      A=options["vqa"]["nans"], H=cx["dim_h"], L=cx["n_layers"], drop_p=cx["drop_p"],
                                      lr=options["optim"]["lr"], device=self.dev,
                                      spec={k: cx.get(k, True) for k in ("v_mult", "v_dist", "v_rank", "a_emb")},
-                                     world_size=self.world)
+                                     world_size=self.world, bf16=args.bf16)
         self.engine.rank = self.rank
         self.engine.init_parameters(seed=42)
         self.gb = options["optim"]["batch_size"]
