@@ -64,8 +64,11 @@ static inline XDesc x_softmax(const float* logits, long long ld, const float* mx
 }
 
 constexpr int NCX_MAX_SEG = 10;
-#ifndef NCX_OCC64
-#define NCX_OCC64 2
+// 64x64 tiles of the row-reduction (TN) form run three workgroups per CU: they serve short reductions (the
+// answer_embedding gradient: 1216 tiles x 16 k-steps), where a third resident workgroup hides the per-workgroup prologue
+// and epilogue and 768 slots hold the launch in two rounds instead of three (measured 89 -> 76 us).
+#ifndef NCX_OCC64_TN
+#define NCX_OCC64_TN 3
 #endif
 constexpr int GEMM_BK = 32;
 
@@ -427,7 +430,7 @@ __device__ __forceinline__ float apply_epilogue(const EpiArgs& e, float v, int r
 // Big tiles get the whole 512-entry register file (one workgroup per CU): at 2 waves per SIMD the 128x128 and
 // 96x128 instantiations spill 90-260 VGPRs.
 template <int BM, int BN, bool A_COLK, bool B_COLK, bool FOLD = false>
-__global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : (BM * BN <= 64 * 64) ? NCX_OCC64 : 2) void seg_gemm_kernel(const GemmArgs args) {
+__global__ __launch_bounds__(256, (BM * BN >= 96 * 128) ? 1 : (BM * BN <= 64 * 64 && !A_COLK && !B_COLK && !FOLD) ? NCX_OCC64_TN : 2) void seg_gemm_kernel(const GemmArgs args) {
     typedef GemmCfg<BM, BN, A_COLK, B_COLK> Cfg;
     constexpr int BK = Cfg::BK, PA = Cfg::PA, PB = Cfg::PB, WM = Cfg::WM, WN = Cfg::WN;
     extern __shared__ __attribute__((aligned(16))) float smem[];
