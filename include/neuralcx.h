@@ -222,6 +222,9 @@ int ncx_profile_end(float* ms, int32_t* ids, int32_t cap);
 /* out6 = {form (0 NT,1 TN,2 NN), M, N, 32-deep k-steps, tile cfg (0 64x64, 1 128x128, 2 96x128),
  *         aligned k-chunks per output tile (1 = no split)} */
 int ncx_plan_query(const ncx_dims* d, int32_t gemm_id, int32_t* out6);
+/* Host-only self-check of the workgroup-id <-> (tile, k-chunk) maps (XCD-aware interleaved layout, chunk-per-XCD
+ * layout with its padding ids): 0 when decode/encode are mutually inverse and cover every (tile, chunk) exactly once. */
+int ncx_wgmap_check(int32_t tiles_m, int32_t tiles_n, int32_t S);
 
 /* Library build id ("neuralcx-hip gfx950 <date>"). */
 const char* ncx_version(void);

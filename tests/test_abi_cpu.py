@@ -51,3 +51,15 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libneuralcx_hip.so")
     with pytest.raises(_lib.NcxError):
         _lib.lib()
+
+
+def test_workgroup_maps_are_bijections():
+    """WgMap (csrc/ncx_gemm.h): every (tile, k-chunk) gets exactly one workgroup id, in the interleaved layout and in
+    the chunk-per-XCD layout (S | 8 with padding ids, 8 | S), for ragged tile counts on either side."""
+    from neuralcx import _lib
+    L = _lib.lib()
+    for tm in (1, 2, 3, 4, 7, 32):
+        for tn in (1, 2, 5, 19, 103):
+            for S in (1, 2, 3, 4, 5, 6, 8, 12, 16, 24):
+                assert L.ncx_wgmap_check(tm, tn, S) == 0, (tm, tn, S)
+    assert L.ncx_wgmap_check(0, 1, 1) < 0

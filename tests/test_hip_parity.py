@@ -112,6 +112,7 @@ def test_ragged_shapes_vs_oracle(B, K, H, L):
 def test_forced_split_k_layouts_vs_oracle(S, monkeypatch):
     """Aligned split-K with every workgroup layout of WgMap (chunk-per-XCD for S | 8 and 8 | S, incl. padding ids;
     the interleaved layout otherwise) on the weight-gradient GEMMs, forced through the planner's experiment hooks."""
+    monkeypatch.setenv("NCX_EXPERIMENT", "1")
     for gid in (0, 1, 4, 6, 7, 9):                       # Gt, Sh, grouped dW1, dE, dW1ak, dW_l
         monkeypatch.setenv("NCX_SPLIT_%d" % gid, str(S))
     d = orc.Dims(dv=70, dq=50, dz=18, A=45, H=128, L=2)

@@ -506,6 +506,7 @@ static void list_uses(const ncx_dims& d, GemmUse* u) {
     u[U_DAGT]  = {FORM_NN, 1, 1, 1, false};                 // (folded into U_DE)
     u[U_DWL]   = {FORM_TN, H, H, ks(M), false};
     u[U_DXL]   = {FORM_NN, M, H, ks(H), false};
+    const bool hooks = experiment_hooks_on();
     for (int i = 0; i < U_COUNT; ++i) {
         // grouped launches (DW1C + DW1S): tiles are counted per column segment
         const long long segs_c[5] = {d.dv, (d.flags & NCX_F_V_MULT) ? d.dv : 0, d.K + 1, d.dz, aemb ? d.A : d.da};
@@ -532,7 +533,7 @@ static void list_uses(const ncx_dims& d, GemmUse* u) {
             u[i].plan = plan_gemm(u[i].form, u[i].M, u[i].N, u[i].ksteps, u[i].allow96);
         }
         if (i == U_MAIN || i == U_FWD_L || i == U_DXL) u[i].plan.split = 1;       // epilogue GEMMs never split
-        {   // experiment hooks: NCX_SPLIT_<id>=S forces S aligned k-chunks, NCX_CFG_<id> the tile config
+        if (hooks) {   // experiment hooks (NCX_EXPERIMENT=1): NCX_SPLIT_<id>=S forces S aligned k-chunks, NCX_CFG_<id> the tile config
             char name[32];
             snprintf(name, sizeof name, "NCX_CFG_%d", i);
             const char* c = getenv(name);
@@ -693,7 +694,7 @@ static int run_gemm(int use_id, GemmArgs& a, int form, const GemmPlan& pl, float
 
 static int run_gemm_impl(GemmArgs& a, int form, const GemmPlan& pl, float* slab, size_t slab_bytes,
                          const float* reduce_bias, hipStream_t s) {
-    { const char* nf = getenv("NCX_NO_FAST"); a.pad_ = nf && atoi(nf) ? 1 : 0; }
+    { const char* nf = hook_env("NCX_NO_FAST"); a.pad_ = nf && atoi(nf) ? 1 : 0; }
     const int np = a.mode == MODE_GROUP ? a.nseg : 1;
     bool any = false;
     for (int i = 0; i < np; ++i) {
@@ -1088,7 +1089,7 @@ static VqaLayout vqa_layout(const ncx_dims& d, const ncx_mutan_params& m, GemmPl
         plans[i] = plan_gemm(FORM_NT, shp[i][0], shp[i][1], shp[i][2], true);
         {   // experiment hook
             char name[32]; snprintf(name, sizeof name, "NCX_VQA_CFG_%d", i);
-            const char* c = getenv(name);
+            const char* c = hook_env(name);
             if (c) { plans[i].cfg = atoi(c); plans[i].split = 1; }
         }
         if (i == 3) { plans[i].cfg = CFG_64x64; plans[i].split = 1; }
@@ -1202,6 +1203,29 @@ int ncx_profile_end(float* ms, int32_t* ids, int32_t cap) {
     free(g_prof.ev); free(g_prof.ids);
     g_prof.ev = nullptr; g_prof.ids = nullptr; g_prof.on = false; g_prof.mask = 0; g_prof.n = 0; g_prof.cap = 0;
     return n < cap ? n : cap;
+}
+
+int ncx_wgmap_check(int32_t tiles_m, int32_t tiles_n, int32_t S) {
+    if (tiles_m < 1 || tiles_n < 1 || S < 1 || (long long)tiles_m * tiles_n * S > (1 << 24)) return NCX_E_DIMS;
+    const WgMap w{tiles_m, tiles_n, S};
+    const int total = tiles_m * tiles_n * S, count = w.count();
+    if (count < total) return 1;
+    unsigned char* seen = (unsigned char*)calloc((size_t)total, 1);
+    if (!seen) return NCX_E_NULL;
+    int bad = 0, nvalid = 0;
+    for (int lw = 0; lw < count && !bad; ++lw) {
+        int tm = -1, tn = -1, z = -1;
+        if (!w.decode(lw, tm, tn, z)) continue;
+        ++nvalid;
+        if (tm < 0 || tm >= tiles_m || tn < 0 || tn >= tiles_n || z < 0 || z >= S) { bad = 2; break; }
+        if (w.encode(tm, tn, z) != lw) { bad = 3; break; }
+        unsigned char& f = seen[((size_t)z * tiles_m + tm) * tiles_n + tn];
+        if (f) { bad = 4; break; }
+        f = 1;
+    }
+    if (!bad && nvalid != total) bad = 5;
+    free(seen);
+    return bad;
 }
 
 int ncx_plan_query(const ncx_dims* d, int32_t gemm_id, int32_t* out6) {

@@ -297,7 +297,7 @@ int bf16_main_forward(const ncx_dims& d, const u16* xc, const u16* wc, const Epi
     // The product is bound by operand delivery (global-load latency x bytes in flight), not by the MFMA pipe: prefer the
     // tile that puts >= 2 workgroups on every CU.  NCX_BF16_NT_CFG (0..3) overrides for experiments.
     int cfg = -1;
-    { const char* e = getenv("NCX_BF16_NT_CFG"); if (e) cfg = atoi(e); }
+    { const char* e = hook_env("NCX_BF16_NT_CFG"); if (e) cfg = atoi(e); }
     if (cfg < 0) {
         const long long t128 = (long long)((M + 127) / 128) * ((d.H + 127) / 128);
         cfg = t128 >= 2LL * num_cus() ? 0 : 3;

@@ -33,3 +33,11 @@ __host__ __device__ __forceinline__ bool dropout_keep(unsigned seed_lo, unsigned
 }
 
 }  // namespace ncx
+
+// The planner's experiment hooks (NCX_CFG_<id>, NCX_SPLIT_<id>, NCX_NO_FAST, NCX_PERSISTENT, NCX_BF16_NT_CFG, ...) are
+// only consulted when NCX_EXPERIMENT=1 is set: the steady-state path then costs one getenv per call instead of ~25.
+#include <stdlib.h>
+namespace ncx {
+static inline bool experiment_hooks_on() { const char* e = getenv("NCX_EXPERIMENT"); return e && e[0] == '1'; }
+static inline const char* hook_env(const char* name) { return experiment_hooks_on() ? getenv(name) : nullptr; }
+}  // namespace ncx

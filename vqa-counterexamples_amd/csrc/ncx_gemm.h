@@ -1005,7 +1005,7 @@ static inline hipError_t launch_seg_gemm(GemmArgs& args, hipStream_t stream) {
         }
         // Measured (grouped dW1, 5856 items on 768 slots): 0.526 ms persistent vs 0.474 ms with one workgroup per
         // item -- the hardware dispatcher balances the unequal items better than a static stride.  Opt-in only.
-        const char* pe = getenv("NCX_PERSISTENT");
+        const char* pe = hook_env("NCX_PERSISTENT");
         if (pe && atoi(pe) && wgs > 2 * slots) grid = slots;
     }
     hipLaunchKernelGGL((seg_gemm_kernel<BM, BN, A_COLK, B_COLK, FOLD>), dim3((unsigned)grid), dim3(256), Cfg::LDS_BYTES, stream, args);
