@@ -153,6 +153,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    fence()                                         # (builds the RCCL communicator before any step)
     for i in range(args.warmup):
         r = step(i)
     fence()
