@@ -48,6 +48,11 @@ extern "C" {
  * the fp32 master weights, inputs and pre-activation gradients) with fp32 accumulation on the bf16 MFMA path;
  * everything else, including Adam on the fp32 master weights, is unchanged.  Needs NCX_F_ALL (no lesions). */
 #define NCX_F_BF16     (1u << 4)
+/* Evaluation loops (eval_model, counterexamples.py:450-490): Gt = W1[:, a_emb_other] . E^T depends on the weights only.
+ * With this bit ncx_forward trusts the Gt left in the workspace by an earlier ncx_forward on the SAME workspace and
+ * weights and skips that GEMM.  The caller owns the invariant (the engine sets it from the second batch of an
+ * evaluation pass on). */
+#define NCX_F_REUSE_GT (1u << 5)
 /* (v_emb / q_emb / z_emb lesions replace INPUTS by uniform noise: the host does that before the call) */
 
 typedef struct ncx_dims {

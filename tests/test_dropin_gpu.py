@@ -250,6 +250,34 @@ def _dp_batch(d, B):
                 gt=torch.from_numpy(rng.integers(0, d.K, size=B)))
 
 
+def test_eval_passes_reuse_gt_and_notice_weight_changes():
+    """NCX_F_REUSE_GT: from the second batch of an evaluation pass on the engine skips Gt = W1[:, a_other] . E^T; the
+    scores must stay bit-identical, and a weight update / a different batch size must invalidate the cached block."""
+    from neuralcx import ops
+    from neuralcx.engine import NeuralCXEngine
+    d = orc.Dims(dv=64, dq=48, dz=16, A=20, H=32, L=1)
+    eng = NeuralCXEngine(K=d.K, dv=d.dv, dq=d.dq, dz=d.dz, da=d.da, A=d.A, H=d.H, L=d.L, drop_p=0.0, lr=1e-2, device=DEV)
+    eng.load_state(orc.init_params(d, seed=5, gain=2.0))
+    mk = lambda B, seed: _dp_batch(d, B) if seed == 3 else None
+    bt = _dp_batch(d, 12)
+    to_batch = lambda t, sl: ops.Batch.from_dense(*[t[k][sl].to(DEV) for k in ("image_features", "q_emb", "z_orig", "z_knns", "a_knns", "answer_aids")])
+    gt = lambda t, sl: t["gt"][sl].to(DEV).to(torch.int32)
+    a, b = slice(0, 6), slice(6, 12)
+    s1 = eng.eval_step(to_batch(bt, a), gt(bt, a))["scores"].clone()
+    s2 = eng.eval_step(to_batch(bt, b), gt(bt, b))["scores"].clone()          # reuses Gt
+    s1b = eng.eval_step(to_batch(bt, a), gt(bt, a))["scores"].clone()         # reuses Gt
+    assert torch.equal(s1, s1b)
+    ref = orc.forward_faithful(orc.init_params(d, seed=5, gain=2.0), d, *[bt[k][b] for k in ("image_features", "q_emb", "z_orig", "z_knns", "a_knns", "answer_aids")])
+    assert float((s2.cpu() - ref).abs().max()) <= 1e-4
+    eng.train_step(to_batch(bt, a), gt(bt, a))                                 # weights move
+    s3 = eng.eval_step(to_batch(bt, a), gt(bt, a))["scores"].clone()
+    fresh = NeuralCXEngine(K=d.K, dv=d.dv, dq=d.dq, dz=d.dz, da=d.da, A=d.A, H=d.H, L=d.L, drop_p=0.0, lr=1e-2, device=DEV)
+    fresh.load_state(eng.state_dict())
+    assert torch.equal(s3, fresh.eval_step(to_batch(bt, a), gt(bt, a))["scores"]) and not torch.equal(s3, s1)
+    s4 = eng.eval_step(to_batch(bt, slice(0, 12)), gt(bt, slice(0, 12)))["scores"]   # other batch size: other layout
+    assert torch.equal(s4, fresh.eval_step(to_batch(bt, slice(0, 12)), gt(bt, slice(0, 12)))["scores"])
+
+
 def test_dp2_hip_engine_equals_dp1():
     """SURVEY 8e: DP-R == DP-1 at the same global batch.  Two gloo ranks share the card (RCCL needs one GPU per rank);
     each runs the HIP engine on its shard with loss_scale = 1/B_global, phased backward + async all-reduce, Adam."""

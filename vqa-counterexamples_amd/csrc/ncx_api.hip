@@ -780,8 +780,8 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
                        bf16_cols(d));
     NCX_HIP_TRY(hipGetLastError());
 
-    // Gt[H, A] = W1[:, a_other] . E^T
-    if (aemb) {
+    // Gt[H, A] = W1[:, a_other] . E^T   (weights only: evaluation passes reuse it, NCX_F_REUSE_GT)
+    if (aemb && !(d.flags & NCX_F_REUSE_GT)) {
         GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = H;
         a.a[0] = x_plain(p->w1 + o.a_other, din, H, d.da);
         a.b[0] = x_plain(p->answer_embedding, d.da, d.A, d.da);
