@@ -166,7 +166,7 @@ def test_cli_real_data_mode_on_reference_format_files(tmp_path, capsys):
     r.vqa.load_state_dict({k[len("vqa_model."):]: v for k, v in state.items() if k.startswith("vqa_model.")})
     r.mutan = type(r.mutan)(r.vqa)
     ids = list(range(40))
-    b, gt = r.get_batch(r.val, ids)
+    b, gt = r.get_batch(r.val, torch.tensor(ids, device=DEV), ids[0])
     ev = r.engine.eval_step(b, gt)
     opt = cli.load_options(args)
     m = NeuralModel(model_spec=opt["cx_model"], dim_h=256, n_layers=1, emb=None, drop_p=0.25, vqa_model=r.vqa, knn_size=24,

@@ -17,11 +17,12 @@ t0 = time.perf_counter(); tps = r.run_epoch(1); print("epoch: %.1f ms/step, %.0f
 stages = {"ids": 0.0, "batch": 0.0, "step": 0.0, "acc": 0.0}
 acc = torch.zeros(3, dtype=torch.float64, device=r.dev)
 n = 0
-for ids in dp.epoch_batches(r.train.N, r.gb, 2, seed=42):
-    t = time.perf_counter(); mine = dp.shard(ids, 0, 1); it = torch.tensor(mine); stages["ids"] += time.perf_counter() - t
-    t = time.perf_counter(); b, gt = r.train.batch(it); torch.cuda.synchronize(); stages["batch"] += time.perf_counter() - t
-    t = time.perf_counter(); res = r.engine.train_step(b, gt, global_batch=len(ids)); torch.cuda.synchronize(); stages["step"] += time.perf_counter() - t
-    t = time.perf_counter(); acc[0] += res["loss"][0].double() * len(ids); acc[1] += res["hits"][1].double(); acc[2] += len(mine); torch.cuda.synchronize(); stages["acc"] += time.perf_counter() - t
+ids_dev, plan = dp.epoch_plan(r.train.N, r.gb, 2, 0, 1, r.dev, seed=42)
+for lo, hi, ng, first in plan:
+    t = time.perf_counter(); it = ids_dev[lo:hi]; stages["ids"] += time.perf_counter() - t
+    t = time.perf_counter(); b, gt = r.get_batch(r.train, it, first); torch.cuda.synchronize(); stages["batch"] += time.perf_counter() - t
+    t = time.perf_counter(); res = r.engine.train_step(b, gt, global_batch=ng); torch.cuda.synchronize(); stages["step"] += time.perf_counter() - t
+    t = time.perf_counter(); acc[0] += res["loss"][0].double() * ng; acc[1] += res["hits"][1].double(); acc[2] += hi - lo; torch.cuda.synchronize(); stages["acc"] += time.perf_counter() - t
     n += 1
 print({k: "%.3f ms" % (v / n * 1e3) for k, v in stages.items()})
 pr = cProfile.Profile(); pr.enable(); r.run_epoch(3); pr.disable()

@@ -166,12 +166,11 @@ class Runner:
                 self.log("Warning: no answer embedding at '{}' (random initialisation)".format(pe))
         self.engine.init_parameters(seed=42, emb=emb)
 
-    def get_batch(self, data, mine):
-        """-> (ops.Batch, gt).  Synthetic: generated on device.  Real: index slices of the resident tables, then the
-        frozen VQA model produces q / z / a (the body of vqa_forward, cx.py:64-104)."""
-        sel = torch.tensor(mine)
+    def get_batch(self, data, sel, first_id):
+        """-> (ops.Batch, gt) for the device tensor `sel` of triplet ids.  Synthetic: generated on device.  Real: index
+        slices of the resident tables, then the frozen VQA model produces q / z / a (the body of vqa_forward, cx.py:64-104)."""
         if self.vqa is None:
-            return data.batch(sel)
+            return data.batch(sel, first_id=first_id)
         img_idx, wids, aids, gt = data.batch_indices(sel)
         with torch.no_grad():
             if self.mutan is not None:
@@ -184,19 +183,18 @@ class Runner:
     # ---- loops ----------------------------------------------------------------------------------------------
     def run_epoch(self, epoch):
         eng, tr = self.engine, self.train
-        batches = dp.epoch_batches(tr.N, self.gb, epoch, seed=42)
+        ids, plan = dp.epoch_plan(tr.N, self.gb, epoch, self.rank, self.world, self.dev, seed=42)   # one H2D copy per epoch
         t0 = time.time(); seen = 0
         acc = torch.zeros(3, dtype=torch.float64, device=self.dev)        # loss*B_local, hits5, count (no host sync)
-        for bi, ids in enumerate(batches):
+        for bi, (lo, hi, n_global, first_id) in enumerate(plan):
             if 0 <= self.args.max_steps <= bi:
                 break
-            mine = dp.shard(ids, self.rank, self.world)
-            if not mine:
+            if hi <= lo:
                 continue
-            b, gt = self.get_batch(tr, mine)
-            r = eng.train_step(b, gt, global_batch=len(ids))
-            acc[0] += r["loss"][0].double() * len(ids); acc[1] += r["hits"][1].double(); acc[2] += len(mine)
-            seen += len(ids)
+            b, gt = self.get_batch(tr, ids[lo:hi], first_id)
+            r = eng.train_step(b, gt, global_batch=n_global)
+            acc[0] += r["loss"][0].double() * n_global; acc[1] += r["hits"][1].double(); acc[2] += hi - lo
+            seen += n_global
             if (bi + 1) % self.args.print_freq == 0:
                 l, _, h5, n = dp.reduce_metrics(float(acc[0]), 0, int(acc[1]), int(acc[2]), self.dev)
                 self.log("Epoch {} train: loss: {:.4f}, recall: {:.4f}, triplets/s: {:.0f}".format(
@@ -210,13 +208,13 @@ class Runner:
     def evaluate(self, data):
         eng = self.engine
         tot = torch.zeros(4, dtype=torch.float64, device=self.dev)
-        for ids in dp.epoch_batches(data.N, self.gb, 0, shuffle=False):
-            mine = dp.shard(ids, self.rank, self.world)
-            if not mine:
+        ids, plan = dp.epoch_plan(data.N, self.gb, 0, self.rank, self.world, self.dev, shuffle=False)
+        for lo, hi, n_global, first_id in plan:
+            if hi <= lo:
                 continue
-            b, gt = self.get_batch(data, mine)
+            b, gt = self.get_batch(data, ids[lo:hi], first_id)
             r = eng.eval_step(b, gt) if self.baseline is None else self.baseline_step(b, gt)
-            tot[0] += r["loss_rows"].double().sum() * len(mine); tot[1] += r["hits"][0]; tot[2] += r["hits"][1]; tot[3] += len(mine)
+            tot[0] += r["loss_rows"].double().sum() * (hi - lo); tot[1] += r["hits"][0]; tot[2] += r["hits"][1]; tot[3] += hi - lo
         l, h1, h5, n = dp.reduce_metrics(float(tot[0]), int(tot[1]), int(tot[2]), int(tot[3]), self.dev)
         return {"loss": l / n, "recall": h5 / n, "recall_1": h1 / n, "recall_5": h5 / n}
 

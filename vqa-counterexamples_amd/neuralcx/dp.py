@@ -41,6 +41,23 @@ def epoch_batches(n_examples: int, global_batch: int, epoch: int, seed: int = 42
     return [ids[i:i + global_batch] for i in range(0, n_examples, global_batch)]
 
 
+def epoch_plan(n_examples: int, global_batch: int, epoch: int, rank: int, world: int, device, seed: int = 42,
+               shuffle: bool = True):
+    """The same batches as `epoch_batches` + `shard`, with ONE host-to-device copy per epoch: returns
+    (ids int64 [n_examples] on `device`, [(lo, hi, global_size, first_id)] per global batch) where ids[lo:hi] is this
+    rank's slice.  Per-step index tensors are then device slices: a pageable host-to-device copy per step would
+    make the host wait for the stream to drain every step."""
+    batches = epoch_batches(n_examples, global_batch, epoch, seed, shuffle)
+    flat = torch.tensor([i for b in batches for i in b], dtype=torch.int64).to(device)
+    plan, off = [], 0
+    for b in batches:
+        n = len(b)
+        lo, hi = n * rank // world, n * (rank + 1) // world
+        plan.append((off + lo, off + hi, n, b[lo] if hi > lo else -1))
+        off += n
+    return flat, plan
+
+
 def shard(batch_ids: List[int], rank: int, world: int) -> List[int]:
     """Contiguous slice of a global batch owned by `rank` (sizes differ by at most one)."""
     n = len(batch_ids)

@@ -51,18 +51,25 @@ class SyntheticCX:
             p = np.exp(logit - logit.max(1, keepdims=True)); p /= p.sum(1, keepdims=True)
             u = rng.random(p.shape[0])[:, None]
             gt[i:i + step] = (p.cumsum(1) < u).sum(1).clip(0, K - 1)
-        self.gt = torch.from_numpy(gt.astype(np.int32))
+        self.gt = torch.from_numpy(gt.astype(np.int32)).to(self.device)
+        self.img_idx = self.img_idx.to(self.device)                    # index arrays live on the device: a batch is
+        self.answer_aids = self.answer_aids.to(self.device)            # three index_selects, no host-to-device copy
+        self._gen = torch.Generator(device=self.device)
 
-    def batch(self, sel: torch.Tensor) -> (Batch, torch.Tensor):
-        """sel: int64 CPU tensor of triplet ids.  q/z/a blocks are generated on device from a per-triplet seed
-        (deterministic for a given id) so a 440 k-triplet set never has to be resident (98 MB of logits per 512)."""
+    def batch(self, sel: torch.Tensor, first_id: Optional[int] = None) -> (Batch, torch.Tensor):
+        """sel: int64 triplet ids, on the device (no host-to-device copy per step) or on the CPU.  q/z/a blocks are
+        generated on device from a per-batch seed (deterministic for a given first id and size) so a 440 k-triplet set
+        never has to be resident (98 MB of logits per 512).  first_id: the first id as a Python int (avoids reading it
+        back from a device tensor)."""
         B, K = sel.numel(), self.K
-        g = torch.Generator(device=self.device)
-        g.manual_seed(self.seed * 1000003 + int(sel[0]) * 7919 + B)
+        if first_id is None:
+            first_id = int(sel[0])
+        sel = sel.to(self.device)
+        g = self._gen
+        g.manual_seed(self.seed * 1000003 + int(first_id) * 7919 + B)
         q = torch.randn(B, self.dq, generator=g, device=self.device) * 0.3
         z_o = torch.randn(B, self.dz, generator=g, device=self.device)
         z_k = torch.randn(B, K, self.dz, generator=g, device=self.device)
         a_k = torch.randn(B, K, self.A, generator=g, device=self.device) * 2.0
-        b = Batch(self.feats, self.img_idx[sel].to(self.device).contiguous(), q, z_o, z_k, a_k,
-                  self.answer_aids[sel].to(self.device).contiguous())
-        return b, self.gt[sel].to(self.device).contiguous()
+        b = Batch(self.feats, self.img_idx.index_select(0, sel), q, z_o, z_k, a_k, self.answer_aids.index_select(0, sel))
+        return b, self.gt.index_select(0, sel)
