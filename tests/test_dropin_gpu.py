@@ -166,7 +166,13 @@ def test_cli_real_data_mode_on_reference_format_files(tmp_path, capsys):
     r.vqa.load_state_dict({k[len("vqa_model."):]: v for k, v in state.items() if k.startswith("vqa_model.")})
     r.mutan = type(r.mutan)(r.vqa)
     ids = list(range(40))
-    b, gt = r.get_batch(r.val, torch.tensor(ids, device=DEV), ids[0])
+    assert r.val.vqa_cache is not None and "cached VQA outputs of the train split" in capsys.readouterr().out
+    sel = torch.tensor(ids, device=DEV)
+    b_cached, _ = r.get_batch(r.val, sel, ids[0])             # per-split cache of the frozen VQA model's outputs
+    r.val.vqa_cache = None
+    b, gt = r.get_batch(r.val, sel, ids[0])                    # produced per batch (--no_vqa_cache)
+    for name in ("q_emb", "z_orig", "z_knns", "a_knns"):
+        assert float((getattr(b, name) - getattr(b_cached, name)).abs().max()) <= 1e-5, name
     ev = r.engine.eval_step(b, gt)
     opt = cli.load_options(args)
     m = NeuralModel(model_spec=opt["cx_model"], dim_h=256, n_layers=1, emb=None, drop_p=0.25, vqa_model=r.vqa, knn_size=24,

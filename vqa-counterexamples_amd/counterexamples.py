@@ -72,6 +72,7 @@ def build_parser():
     p.add_argument("--syn_val", type=int, default=4096)
     p.add_argument("--syn_images", type=int, default=82783)
     p.add_argument("--max_steps", type=int, default=-1, help="stop an epoch early (smoke runs)")
+    p.add_argument("--no_vqa_cache", action="store_true", help="produce q / z / answer logits per batch instead of once per split")
     p.add_argument("--bf16", action="store_true", help="bf16 operands on the two dominant GEMMs (fp32 accumulate / master weights)")
     p.add_argument("--path_trainset", type=str, default=None, help="overrides vqa.path_trainset of the YAML")
     p.add_argument("--path_features", type=str, default=None, help="overrides coco.path_features / path_raw of the YAML")
@@ -165,20 +166,34 @@ class Runner:
             else:
                 self.log("Warning: no answer embedding at '{}' (random initialisation)".format(pe))
         self.engine.init_parameters(seed=42, emb=emb)
+        if not a.no_vqa_cache:                      # frozen VQA model: its outputs are per-example constants
+            seen = set()
+            for name, ds in (("train", self.train), ("val", self.val), ("test", self.test)):
+                if id(ds) in seen:
+                    continue
+                seen.add(id(ds))
+                nbytes = ds.cache_vqa_outputs(lambda img_idx, wids, ds=ds: self._vqa_outputs(ds, img_idx, wids))
+                self.log("=> cached VQA outputs of the {} split: {} examples, {:.2f} GB".format(name, ds.N, nbytes / 1e9))
 
-    def get_batch(self, data, sel, first_id):
-        """-> (ops.Batch, gt) for the device tensor `sel` of triplet ids.  Synthetic: generated on device.  Real: index
-        slices of the resident tables, then the frozen VQA model produces q / z / a (the body of vqa_forward, cx.py:64-104)."""
-        if self.vqa is None:
-            return data.batch(sel, first_id=first_id)
-        img_idx, wids, aids, gt = data.batch_indices(sel)
+    def _vqa_outputs(self, data, img_idx, wids):
+        """q_emb, z_orig, z_knns, a_knns of the frozen VQA model for a block of examples (vqa_forward, cx.py:64-104)."""
         with torch.no_grad():
             if self.mutan is not None:
                 q = self.vqa.seq2vec(wids).float().contiguous()
-                return self.engine.make_batch_from_vqa(data.feats, img_idx, q, aids, self.mutan), gt
+                _, z_o, a_k, z_k = ops.vqa_forward(data.feats, img_idx, q, self.mutan, want_a_orig=False)
+                return q, z_o, z_k, a_k
             _, z_o, a_k, z_k, q = self._torch_vqa.vqa_forward(data.dense_features(img_idx), wids)
-            return ops.Batch(data.feats, img_idx, q.float().contiguous(), z_o.float().contiguous(),
-                             z_k.float().contiguous(), a_k.float().contiguous(), aids), gt
+            return q.float().contiguous(), z_o.float().contiguous(), z_k.float().contiguous(), a_k.float().contiguous()
+
+    def get_batch(self, data, sel, first_id):
+        """-> (ops.Batch, gt) for the device tensor `sel` of triplet ids.  Synthetic: generated on device.  Real: index
+        slices of the resident tables; q / z / a come from the per-split cache of the frozen VQA model's outputs, or
+        (--no_vqa_cache) are produced per batch."""
+        if self.vqa is None:
+            return data.batch(sel, first_id=first_id)
+        img_idx, wids, aids, gt = data.batch_indices(sel)
+        q, z_o, z_k, a_k = data.cached_vqa(sel) if data.vqa_cache is not None else self._vqa_outputs(data, img_idx, wids)
+        return ops.Batch(data.feats, img_idx, q, z_o, z_k, a_k, aids), gt
 
     # ---- loops ----------------------------------------------------------------------------------------------
     def run_epoch(self, epoch):
