@@ -67,6 +67,11 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise NcxError("HIP library not built: %s is missing. Run `python -c 'import __graft_entry__ as g; "
                        "g.build()'` or `make -C vqa-counterexamples_amd`." % LIB_PATH)
+    # The library shares the process's HIP runtime with PyTorch (streams and device pointers cross the boundary), and
+    # PyTorch-ROCm ships its own libamdhip64: import torch FIRST so that the dynamic linker resolves this library's
+    # libamdhip64.so.7 to the copy torch already loaded.  Loaded the other way round, the process ends up with two HIP
+    # runtimes and every launch on a torch stream fails with hipErrorNoDevice.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     L.ncx_version.restype = C.c_char_p
     L.ncx_input_size.restype = C.c_int64
