@@ -151,7 +151,14 @@ class NeuralCXEngine:
                 h2 = torch.distributed.all_reduce(self.grads.flat[n_emb:], group=self.pg, async_op=True)
                 h1.wait()
                 ops.backward(d, batch, f, self._ws, r["dscores"], self.grads.fields(), phase=4)
+                # answer_embedding's gradient is complete on every rank: its Adam slice also runs under bucket 2
+                ops.adam_step(self.params.flat[:n_emb], self.grads.flat[:n_emb], self.exp_avg[:n_emb], self.exp_avg_sq[:n_emb],
+                              self.step_count, lr=self.lr)
                 h2.wait()
+                ops.adam_step(self.params.flat[n_emb:], self.grads.flat[n_emb:], self.exp_avg[n_emb:], self.exp_avg_sq[n_emb:],
+                              self.step_count, lr=self.lr)
+                r["scores"] = scores
+                return r
             else:                                   # a_emb lesion: the embedding gradient is zero everywhere
                 ops.backward(d, batch, f, self._ws, r["dscores"], self.grads.fields(), phase=4)
                 torch.distributed.all_reduce(self.grads.flat[n_emb:], group=self.pg)
