@@ -238,6 +238,57 @@ def test_full_dims_property_checks():
     assert torch.equal(ops.forward(dims, b, p, ws), s1)
 
 
+def test_full_dims_backward_is_additive_over_triplets():
+    """BASELINE size (B=512, full widths, H=256, every split-K / tile path of the real plan): the gradient of the batch
+    equals the sum of the gradients of its two halves at the same loss scale (triplets are independent; linearity), and
+    the first triplets' logits equal the CPU oracle's.  Ties the full-size launch plan to the small cases that are
+    checked against the reference's own outputs (g2_full_* fixtures)."""
+    from neuralcx import ops
+    d = orc.Dims()
+    B = 512
+    rng = np.random.default_rng(5)
+    torch.manual_seed(5)
+    n_img = 4096
+    feats = (torch.randn(n_img, d.dv).abs() * 0.45)
+    idx = torch.from_numpy(rng.integers(0, n_img, size=(B, d.K + 1)).astype(np.int32))
+    q, zo, zk, ak = torch.randn(B, d.dq) * 0.3, torch.randn(B, d.dz), torch.randn(B, d.K, d.dz), torch.randn(B, d.K, d.A) * 2
+    aid = torch.from_numpy(rng.integers(0, d.A, size=B).astype(np.int32))
+    gt = torch.from_numpy(rng.integers(0, d.K, size=B).astype(np.int32))
+    params = orc.init_params(d, seed=42)
+    p = to_dev_params(params)
+    fd = feats.to(dev())
+
+    def grads_of(sl):
+        b = ops.Batch(fd, idx[sl].to(dev()).contiguous(), q[sl].to(dev()).contiguous(), zo[sl].to(dev()).contiguous(),
+                      zk[sl].to(dev()).contiguous(), ak[sl].to(dev()).contiguous(), aid[sl].to(dev()).contiguous())
+        dims = ops.make_dims(b, H=d.H, L=d.L, da=d.da, A=d.A)
+        ws = ops.alloc_workspace(dims, dev())
+        scores = ops.forward(dims, b, p, ws)
+        lr = ops.ranking_loss(scores, gt[sl].to(dev()), scale=1.0 / B)
+        g = {k: torch.full_like(v, float("nan")) for k, v in p.items()}
+        ops.backward(dims, b, p, ws, lr["dscores"], g)
+        return scores, g
+
+    s_all, g_all = grads_of(slice(0, B))
+    _, g_lo = grads_of(slice(0, B // 2))
+    _, g_hi = grads_of(slice(B // 2, B))
+    for k in g_all:
+        tot = g_lo[k] + g_hi[k]
+        # fp32 sums of 12 288 terms in two different groupings; the embedding gradient (max 1e-5 here) is a small
+        # difference of large terms (softmax rows sum to one), hence the absolute floor, as for the oracle comparisons
+        tol = 1e-4 * max(float(g_all[k].abs().max()), 1e-3)
+        err = (g_all[k] - tot).abs().flatten()
+        # the halves run another tile plan (M = 6144), so pre-activations differ in the last bit and a handful of the 3.1 M
+        # ReLU inputs within 1e-6 of zero switch: 99.9 % of the entries within `tol`, the whole tensor within 1e-3 (Frobenius)
+        kth = max(1, int(err.numel() * 0.999))
+        assert torch.isfinite(g_all[k]).all(), k
+        assert float(err.kthvalue(kth).values) <= tol, (k, float(err.kthvalue(kth).values), tol)
+        assert float(err.norm()) <= 1e-3 * float(g_all[k].norm()) + 1e-7, (k, float(err.norm()), float(g_all[k].norm()))
+    n = 3
+    s_ref = orc.forward_faithful(params, d, feats[idx[:n].long()], q[:n], zo[:n], zk[:n], ak[:n], aid[:n].long())
+    assert float((s_all[:n].cpu() - s_ref).abs().max()) <= 1e-4
+
+
 def test_loss_rank_kernel_known_answers():
     from neuralcx import ops
     g = dict(np.load(GOLDEN + "/g4_recall_loss.npz"))
