@@ -102,20 +102,22 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64) ? 4 : (BM * BN <= 64 * 12
         }
     };
 
+    // Kc is a multiple of 128: an even number of K-steps.  Every load and LDS store of the loop is UNCONDITIONAL (the
+    // K-step index is clamped, the surplus tiles of the last iteration are never read): a branch around the loads made
+    // the compiler drain vmcnt to 0 before issuing them, i.e. one K-step in flight and the full latency exposed.
     const int nk = Kc / 64;
     issue(ra0, rb0, 0);
-    if (nk > 1) issue(ra1, rb1, 1);
+    issue(ra1, rb1, 1);
     stash(ra0, rb0, 0);
     __syncthreads();
     for (int t = 0; t < nk; t += 2) {
-        if (t + 2 < nk) issue(ra0, rb0, t + 2);
+        issue(ra0, rb0, min(t + 2, nk - 1));
         compute(0);
-        if (t + 1 < nk) stash(ra1, rb1, 1);
+        stash(ra1, rb1, 1);
         __syncthreads();
-        if (t + 1 >= nk) break;
-        if (t + 3 < nk) issue(ra1, rb1, t + 3);
+        issue(ra1, rb1, min(t + 3, nk - 1));
         compute(1);
-        if (t + 2 < nk) stash(ra0, rb0, 0);
+        stash(ra0, rb0, 0);
         __syncthreads();
     }
     // row-block loop kept rolled (compile-time-indexed selects pick the block's accumulators): fully unrolled, the 64
@@ -175,20 +177,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const u16* __restr
         for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     u32x4 ra0[4], rb0[4], ra1[4], rb1[4];
-    auto issue = [&](u32x4 (&ra)[4], u32x4 (&rb)[4], int kt) __attribute__((always_inline)) {
+    unsigned km0[4], km1[4];
+    auto issue_m = [&](u32x4 (&ra)[4], u32x4 (&rb)[4], unsigned (&km)[4], int kt) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = k0 + kt * 64 + lr + 16 * i, kc = min(k, rows - 1);
+            const unsigned keep = k < k1 ? 0xFFFFFFFFu : 0u;             // (AND mask at store time: no branch around the load)
             ra[i] = *(const u32x4*)(pa + (long long)kc * lda);
             rb[i] = *(const u32x4*)(pb + (long long)kc * ldb);
-            if (k >= k1) { ra[i] = u32x4{0u, 0u, 0u, 0u}; rb[i] = u32x4{0u, 0u, 0u, 0u}; }
+            km[i] = keep;
         }
     };
-    auto stash = [&](const u32x4 (&ra)[4], const u32x4 (&rb)[4], int buf) __attribute__((always_inline)) {
+    auto stash_m = [&](const u32x4 (&ra)[4], const u32x4 (&rb)[4], const unsigned (&km)[4], int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *(u32x4*)(lds_a + buf * A_BYTES + (lr + 16 * i) * TN_PITCH + lc * 16) = ra[i];
-            *(u32x4*)(lds_b + buf * B_BYTES + (lr + 16 * i) * TN_PITCH + lc * 16) = rb[i];
+            *(u32x4*)(lds_a + buf * A_BYTES + (lr + 16 * i) * TN_PITCH + lc * 16) = ra[i] & km[i];
+            *(u32x4*)(lds_b + buf * B_BYTES + (lr + 16 * i) * TN_PITCH + lc * 16) = rb[i] & km[i];
         }
     };
     typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
@@ -221,20 +225,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const u16* __restr
         }
     };
 
-    const int nk = (k1 - k0 + 63) / 64;
-    issue(ra0, rb0, 0);
-    if (nk > 1) issue(ra1, rb1, 1);
-    stash(ra0, rb0, 0);
+    // K-steps rounded up to an even count: rows at or beyond k1 load as zeros, so a surplus step adds nothing; all loads
+    // and LDS stores are unconditional (see the NT kernel)
+    const int nk = ((k1 - k0 + 63) / 64 + 1) & ~1;
+    issue_m(ra0, rb0, km0, 0);
+    issue_m(ra1, rb1, km1, 1);
+    stash_m(ra0, rb0, km0, 0);
     __syncthreads();
     for (int t2 = 0; t2 < nk; t2 += 2) {
-        if (t2 + 2 < nk) issue(ra0, rb0, t2 + 2);
+        issue_m(ra0, rb0, km0, t2 + 2);
         compute(0);
-        if (t2 + 1 < nk) stash(ra1, rb1, 1);
+        stash_m(ra1, rb1, km1, 1);
         __syncthreads();
-        if (t2 + 1 >= nk) break;
-        if (t2 + 3 < nk) issue(ra1, rb1, t2 + 3);
+        issue_m(ra1, rb1, km1, t2 + 3);
         compute(1);
-        if (t2 + 2 < nk) stash(ra0, rb0, 0);
+        stash_m(ra0, rb0, km0, 0);
         __syncthreads();
     }
     float* dst = slab + (long long)z * H * Kc;
