@@ -117,6 +117,48 @@ def test_engine_training_matches_oracle_training():
     assert abs(float(ev["loss"]) - l_held) <= 1e-3
 
 
+def test_full_width_training_run_matches_reference_faithful_cpu_training():
+    """north_star: "Recall@5 matching the reference to +-0.1 on identical synthetic data".  Full model widths (2048-d
+    features, 2400-d question / answer embeddings, 2000 answers, H=256, L=1, dropout 0.25), 40 Adam steps of batch 32
+    (BASELINE configs[0]'s batch) on planted synthetic triplets: the HIP engine and the CPU oracle's reference-faithful
+    training (24-iteration cat + Linear loop, autograd, Adam; shared counter-based dropout masks) must produce the same
+    loss curve (<= 2e-4 per step) and the same Recall@1 / Recall@5 on 128 held-out triplets."""
+    from neuralcx import ops
+    from neuralcx.engine import NeuralCXEngine
+    from neuralcx.synth import SyntheticCX
+    d = orc.Dims()                                           # K=24, dv=2048, dq=2400, dz=360, da=2400, A=2000, H=256, L=1
+    B, steps, p_drop, lr = 32, 40, 0.25, 1e-3
+    data = SyntheticCX(n_triplets=B * steps + 128, n_img=1024, seed=77, device=DEV)
+    eng = NeuralCXEngine(H=d.H, L=d.L, drop_p=p_drop, lr=lr, device=DEV)
+    params = orc.init_params(d, seed=42)
+    eng.load_state(params)
+    st = orc.AdamState()
+    cur = {k: v.clone() for k, v in params.items()}
+    feats_cpu = data.feats.cpu()
+
+    def cpu_batch(b, gt):
+        return dict(image_features=feats_cpu[b.img_idx.cpu().long()], q_emb=b.q_emb.cpu(), z_orig=b.z_orig.cpu(), z_knns=b.z_knns.cpu(),
+                    a_knns=b.a_knns.cpu(), answer_aids=b.answer_aids.cpu().long(), gt=gt.cpu().long())
+    worst = 0.0
+    for s in range(steps):
+        b, gt = data.batch(torch.arange(s * B, (s + 1) * B, device=DEV), first_id=s * B)
+        r = eng.train_step(b, gt)
+        seed = (eng.seed << 32) ^ eng.step_count
+        masks = [orc.dropout_keep_mask(seed, 1, B * d.K, d.H, p_drop)]
+        cur, _, l_ref, _ = orc.train_step(cur, d, cpu_batch(b, gt), st, lr=lr, drop_p=p_drop, keep_masks=masks)
+        worst = max(worst, abs(float(r["loss"]) - float(l_ref)))
+        assert worst <= 2e-4, (s, float(r["loss"]), float(l_ref))
+    hb, hgt = data.batch(torch.arange(B * steps, B * steps + 128, device=DEV), first_id=B * steps)
+    ev = eng.eval_step(hb, hgt)
+    hc = cpu_batch(hb, hgt)
+    s_ref = orc.forward_faithful(cur, d, hc["image_features"], hc["q_emb"], hc["z_orig"], hc["z_knns"], hc["a_knns"], hc["answer_aids"])
+    for k, i in ((1, 0), (5, 1)):
+        r_hip = 100.0 * int(ev["hits"][i]) / 128
+        r_ref = 100.0 * float(orc.recall_at_k(s_ref, hc["gt"], k).sum()) / 128
+        assert abs(r_hip - r_ref) <= 0.1 + 1e-9, (k, r_hip, r_ref)
+    assert abs(float(ev["loss"]) - float(orc.ranking_loss(s_ref, hc["gt"]))) <= 1e-3
+
+
 def test_cli_synthetic_smoke(tmp_path, capsys):
     import counterexamples as cli
     cli.main(["--synthetic", "--path_opt", os.path.join(PKG, "options", "cx", "neuralcx_256_1_all.yaml"), "-b", "64",
