@@ -175,6 +175,8 @@ def test_cli_synthetic_smoke(tmp_path, capsys):
         info = torch.load(os.path.join(base, sub, "info.ckpt"))
         assert {"loss", "recall"} <= set(info[-1])
     assert os.path.exists(os.path.join(base, "final_results.txt"))
+    runs = os.path.join(str(tmp_path), "runs", os.path.basename(base))
+    assert os.path.exists(os.path.join(runs, "val.jsonl"))            # scalars the reference sends to tensorboard
 
 
 def test_cli_real_data_mode_on_reference_format_files(tmp_path, capsys):

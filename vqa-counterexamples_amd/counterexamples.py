@@ -112,6 +112,7 @@ class Runner:
         self.engine.init_parameters(seed=42)
         self.gb = options["optim"]["batch_size"]
         self.baseline = None if args.cx_model == "NeuralModel" else args.cx_model
+        self.runs_dir = None
 
     def log(self, *a):
         if self.rank == 0:
@@ -214,6 +215,8 @@ class Runner:
                 l, _, h5, n = dp.reduce_metrics(float(acc[0]), 0, int(acc[1]), int(acc[2]), self.dev)
                 self.log("Epoch {} train: loss: {:.4f}, recall: {:.4f}, triplets/s: {:.0f}".format(
                     epoch, l / max(n, 1), h5 / max(n, 1), seen / (time.time() - t0)))
+                self.scalars("train", epoch, (epoch - 1) * len(plan) + bi + 1,
+                             dict(loss=l / max(n, 1), recall=h5 / max(n, 1), triplets_per_s=seen / (time.time() - t0)))
                 acc.zero_()
             if self.args.eval_freq > 0 and (bi + 1) % self.args.eval_freq == 0:
                 self.report("val", epoch, self.evaluate(self.val))
@@ -246,8 +249,18 @@ class Runner:
         r["scores"] = scores
         return r
 
-    def report(self, mode, epoch, metrics):
+    def report(self, mode, epoch, metrics, step=None):
         self.log("Epoch {} {}: {}".format(epoch, mode, "".join("{}: {:.4f}, ".format(k, v) for k, v in metrics.items())))
+        self.scalars(mode, epoch, step, metrics)
+
+    def scalars(self, mode, epoch, step, metrics):
+        """The reference's log_results also feeds tensorboard writers under runs/<run>/{train,val} (counterexamples.py:
+        168-169,493-498); the package is not available offline, so the same scalars go to runs/<run>/<mode>.jsonl."""
+        if self.rank != 0 or self.runs_dir is None:
+            return
+        os.makedirs(self.runs_dir, exist_ok=True)
+        with open(os.path.join(self.runs_dir, "%s.jsonl" % ("val" if mode == "test" else mode)), "a") as f:
+            f.write(json.dumps(dict(mode=mode, epoch=epoch, step=step, **{k: float(v) for k, v in metrics.items()})) + "\n")
 
     # ---- checkpoints (counterexamples.py:550-580) -------------------------------------------------------------
     def save(self, save_dir, info, is_best):
@@ -286,6 +299,7 @@ def main(argv=None):
     r = Runner(args, options)
     run = args.resume or "{}_{}".format(options["cx_model"].get("name", "neuralcx"), time.strftime("%m%d_%H%M%S"))
     save_dir = os.path.join(args.project_dir, "logs", "cx", run)
+    r.runs_dir = os.path.join(args.project_dir, "runs", run)
     if args.synthetic:
         r.load_synthetic()
     else:
