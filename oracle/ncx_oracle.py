@@ -197,12 +197,46 @@ class _Bf16Product(torch.autograd.Function):
         return None, _bf(g).t() @ xb
 
 
+class _Bf16GtProduct(torch.autograd.Function):
+    """Gt = bf16(W1ak) . bf16(E)^T;  grad_W1ak = bf16(g) . bf16(E),  grad_E = bf16(g)^T . bf16(W1ak)."""
+
+    @staticmethod
+    def forward(ctx, w, e):
+        wb, eb = _bf(w), _bf(e)
+        ctx.save_for_backward(wb, eb)
+        return wb @ eb.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        wb, eb = ctx.saved_tensors
+        gb = _bf(g)
+        return gb @ eb, gb.t() @ wb
+
+
+class _SharedAnswerEmbedding(torch.autograd.Function):
+    """E[aid] . W1agt^T of the per-triplet shared segments: fp32 forward and fp32 grad_W1agt (they ride in the fp32 Sh /
+    shared-column GEMMs); grad_E = bf16(dGgt)^T . bf16(W1agt) with dGgt[h][a] = sum over triplets with answer a of g[b][h]
+    (the second half of the stacked bf16 dE product)."""
+
+    @staticmethod
+    def forward(ctx, e, w, aids):
+        ctx.save_for_backward(e, w, aids)
+        return F.embedding(aids, e) @ w.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        e, w, aids = ctx.saved_tensors
+        dggt = torch.zeros(w.shape[0], e.shape[0]).index_add_(1, aids, g.t().contiguous())
+        return _bf(dggt).t() @ _bf(w), g.t() @ F.embedding(aids, e), None
+
+
 def forward_bf16(params: Dict[str, torch.Tensor], d: Dims, image_features, q_emb, z_orig, z_knns, a_knns, answer_aids,
                  drop_p: float = 0.0, keep_masks: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
     """scores[B,K] of the NCX_F_BF16 variant: the same network as forward_faithful (vqa/models/cx.py:261-333) in its
-    segmented form -- the four per-triplet segments and Gt = W1[:, a_emb_other] . E^T in fp32, the five per-candidate
+    segmented form -- the four per-triplet segments in fp32; Gt = W1[:, a_emb_other] . E^T and the five per-candidate
     segments [v_k | v_o*v_k | dist, rank | z_k | softmax(a_k)] against [W1 slices | Gt] with BOTH operands rounded to
-    bf16 and fp32 accumulation; hidden layers >= 2, `out`, loss and Adam in fp32."""
+    bf16 and fp32 accumulation; the answer-embedding gradients from bf16 images of dGt | dGgt, E and W1[:, a_*]; hidden
+    layers >= 2, `out`, loss and Adam in fp32."""
     B, K = image_features.shape[0], d.K
     W1, b1, E = params["linear_1.weight"], params["linear_1.bias"], params["answer_embedding.weight"]
     o, c = {}, 0
@@ -211,9 +245,9 @@ def forward_bf16(params: Dict[str, torch.Tensor], d: Dims, image_features, q_emb
         o[name] = (c, c + n); c += n
     cols = lambda n: W1[:, o[n][0]:o[n][1]]
     v_o, v_k = image_features[:, 0], image_features[:, 1:]
-    shared = torch.cat((v_o, q_emb, z_orig, F.embedding(answer_aids, E)), 1) @ \
-        torch.cat((cols("v_orig"), cols("q_emb"), cols("z_orig"), cols("a_gt")), 1).t() + b1
-    gt_mat = cols("a_other") @ E.t()                                                        # [H, A]
+    shared = torch.cat((v_o, q_emb, z_orig), 1) @ torch.cat((cols("v_orig"), cols("q_emb"), cols("z_orig")), 1).t() + b1 \
+        + _SharedAnswerEmbedding.apply(E, cols("a_gt"), answer_aids)
+    gt_mat = _Bf16GtProduct.apply(cols("a_other"), E)                                       # [H, A]
     dist = (v_o[:, None, :] - v_k + 1e-6).norm(dim=2, keepdim=True)                         # cx.py:300
     rank = torch.eye(K).view(1, K, K).expand(B, K, K)                                       # cx.py:304-305
     xc = torch.cat((v_k, v_o[:, None, :] * v_k, dist, rank, z_knns, F.softmax(a_knns, dim=-1)), 2).reshape(B * K, -1)

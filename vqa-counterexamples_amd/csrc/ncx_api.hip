@@ -608,6 +608,7 @@ WsLayout ws_layout(const ncx_dims& d) {
     if (d.flags & NCX_F_BF16) {                          // packed bf16 operands of the two dominant GEMMs (ncx_bf16.h)
         w.xc = take(bf16_xc_bytes(d)); w.wc = take(bf16_wc_bytes(d));
         w.dpre_bf = take(bf16_dpre_bytes(d)); w.bf_slab = take(bf16_slab_bytes(d));
+        w.bf_emb = take(bf16_emb_bytes(d));
     }
     w.total = off;
     return w;
@@ -781,7 +782,13 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
     NCX_HIP_TRY(hipGetLastError());
 
     // Gt[H, A] = W1[:, a_other] . E^T   (weights only: evaluation passes reuse it, NCX_F_REUSE_GT)
-    if (aemb && !(d.flags & NCX_F_REUSE_GT)) {
+    if (aemb && bf16 && !(d.flags & NCX_F_REUSE_GT)) {       // bf16 copies of E / W1[:, a_*] (also the backward's operands)
+        const Bf16Emb m = bf16_emb_layout(d, ws + w.bf_emb);
+        rc = bf16_pack_embedding(d, p->answer_embedding, p->w1, m, s2); if (rc) return rc;
+        rc = prof_open(U_GT, s2); if (rc) return rc;
+        rc = bf16_gt(d, m, gt, s2); if (rc) return rc;
+        rc = prof_close(U_GT, s2); if (rc) return rc;
+    } else if (aemb && !(d.flags & NCX_F_REUSE_GT)) {
         GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = H;
         a.a[0] = x_plain(p->w1 + o.a_other, din, H, d.da);
         a.b[0] = x_plain(p->answer_embedding, d.da, d.A, d.da);
@@ -1018,7 +1025,13 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
         // dW1[:, a_other] = dGt . E and dE are independent consumers of dGt: when both run in this call, the former
         // goes to the side stream (own slab) and overlaps the latter
         SideStream* ss = (do1 && do2) ? side_stream() : nullptr;
-        if (do2) {   // dW1[:, a_other][n][j] = sum_a dGt[n][a] E[a][j]
+        const bool bf16e = d.flags & NCX_F_BF16;
+        const Bf16Emb bm = bf16e ? bf16_emb_layout(d, ws + w.bf_emb) : Bf16Emb{};
+        if (do2 && bf16e) {
+            rc = prof_open(U_DW1AK, s); if (rc) return rc;
+            rc = bf16_dw1ak(d, bm, dgt, g->w1, s); if (rc) return rc;
+            rc = prof_close(U_DW1AK, s); if (rc) return rc;
+        } else if (do2) {   // dW1[:, a_other][n][j] = sum_a dGt[n][a] E[a][j]
             GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = H;
             a.a[0] = x_plain(dgt, d.A, H, d.A); a.b[0] = x_plain(p->answer_embedding, d.da, d.A, d.da); a.klen[0] = d.A;
             a.out[0] = g->w1 + o.a_other; a.ldo[0] = din; a.n_cols[0] = d.da;
@@ -1031,7 +1044,11 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
             hipLaunchKernelGGL(k_scatter_dsh_by_answer, dim3(d.B), dim3(256), 0, s, (const float*)dsh, in->answer_aids, d.B, H, d.A, dagt);
             NCX_HIP_TRY(hipGetLastError());
         }
-        if ((do1 && !skip_de) || only_de) {   // dE[a][j] = sum_n dGt[n][a] W1ak[n][j] + sum_n dGgt[n][a] W1agt[n][j]
+        if (((do1 && !skip_de) || only_de) && bf16e) {
+            rc = prof_open(U_DE, s); if (rc) return rc;
+            rc = bf16_de(d, bm, dgt, g->answer_embedding, s); if (rc) return rc;
+            rc = prof_close(U_DE, s); if (rc) return rc;
+        } else if ((do1 && !skip_de) || only_de) {   // dE[a][j] = sum_n dGt[n][a] W1ak[n][j] + sum_n dGgt[n][a] W1agt[n][j]
             GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 2; a.M = d.A;
             a.a[0] = x_plain(dgt, d.A, H, d.A);  a.b[0] = x_plain(p->w1 + o.a_other, din, H, d.da); a.klen[0] = H;
             a.a[1] = x_plain(dagt, d.A, H, d.A); a.b[1] = x_plain(p->w1 + o.a_gt, din, H, d.da);    a.klen[1] = H;

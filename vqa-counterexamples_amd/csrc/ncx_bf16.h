@@ -36,6 +36,28 @@ static inline size_t bf16_wc_bytes(const ncx_dims& d) { return (size_t)((d.H + 1
 static inline size_t bf16_dpre_bytes(const ncx_dims& d) { return (size_t)d.B * d.K * ((d.H + 127) / 128 * 128) * 2; }
 static inline size_t bf16_slab_bytes(const ncx_dims& d) { return (size_t)BF16_SPLIT * d.H * bf16_cols(d).kc * 4; }
 
+// The answer-embedding products of the variant (Gt forward; dW1[:, a_other] and dE backward) take bf16 copies of the
+// weights too: E [A][dap], E^T [da][Ap], [W1ak; W1agt] [2H][dap] and the bf16 image of [dGt; dGgt] [2H][Ap]
+// (dap / Ap: da / A rounded up to 128).
+struct Bf16Emb { u16* e_bf; u16* et_bf; u16* w1a_bf; u16* dg_bf; int dap, Ap; };
+static inline int bf16_up128(int x) { return (x + 127) / 128 * 128; }
+static inline size_t bf16_emb_bytes(const ncx_dims& d) {
+    const size_t dap = bf16_up128(d.da), Ap = bf16_up128(d.A);
+    return ((size_t)d.A * dap + (size_t)d.da * Ap + (size_t)2 * d.H * dap + (size_t)2 * d.H * Ap) * 2 + 4 * 256;
+}
+static inline Bf16Emb bf16_emb_layout(const ncx_dims& d, char* base) {
+    Bf16Emb m; m.dap = bf16_up128(d.da); m.Ap = bf16_up128(d.A);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base + off; off = (off + bytes + 255) / 256 * 256; return (u16*)p; };
+    m.e_bf = take((size_t)d.A * m.dap * 2); m.et_bf = take((size_t)d.da * m.Ap * 2);
+    m.w1a_bf = take((size_t)2 * d.H * m.dap * 2); m.dg_bf = take((size_t)2 * d.H * m.Ap * 2);
+    return m;
+}
+int bf16_pack_embedding(const ncx_dims& d, const float* E, const float* w1, const Bf16Emb& m, hipStream_t s);
+int bf16_gt(const ncx_dims& d, const Bf16Emb& m, float* gt, hipStream_t s);
+int bf16_dw1ak(const ncx_dims& d, const Bf16Emb& m, const float* dgt_dagt, float* g_w1, hipStream_t s);
+int bf16_de(const ncx_dims& d, const Bf16Emb& m, const float* dgt_dagt, float* g_E, hipStream_t s);
+
 // Wc = bf16([W1 candidate-segment columns | Gt]), zero in the padding columns and rows (rows padded to 128)
 int bf16_pack_wc(const ncx_dims& d, const float* w1, const float* gt, u16* wc, hipStream_t s);
 // h1 = epilogue(Xc . Wc^T): out [M, H] fp32

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64) ? 4 : (BM * BN <= 64 * 12
 constexpr int TN_PITCH = 288;
 template <int BM, int BN>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const u16* __restrict__ A, int lda, const u16* __restrict__ B, int ldb,
-                                                              int rows, int chunk_rows, int tiles_m, float* __restrict__ slab,
+                                                              int rows, int chunk_rows, int tiles_m, int S, float* __restrict__ slab,
                                                               int H, int Kc) {
     constexpr int WM = BM / 32, WN = BN / 32;
     constexpr int A_BYTES = 64 * TN_PITCH, B_BYTES = 64 * TN_PITCH;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const u16* __restr
     unsigned char* const lds_b = smem_bf16 + 2 * A_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int wm0 = (wave >> 1) * (BM / 2), wn0 = (wave & 1) * (BN / 2);
-    const int z = blockIdx.x & 7, t = blockIdx.x >> 3;
+    const int z = blockIdx.x % S, t = blockIdx.x / S;
     const int tm = t % tiles_m, tn = t / tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
     const int k0 = z * chunk_rows, k1 = min(k0 + chunk_rows, rows);
@@ -285,7 +285,8 @@ int bf16_pack_wc(const ncx_dims& d, const float* w1, const float* gt, u16* wc, h
 }
 
 template <int BM, int BN>
-static int launch_bf16_nt(const u16* xc, int M, const u16* wc, int N, int kc, const EpiArgs& epi, float* out, hipStream_t s) {
+static int launch_bf16_nt(const u16* xc, int M, const u16* wc, int N, int kc, const EpiArgs& epi, float* out, hipStream_t s,
+                          long long ldo = 0) {
     const int lds = 2 * (BM + BN) * NT_PITCH;
     static bool attr = false;
     if (!attr) {
@@ -293,7 +294,7 @@ static int launch_bf16_nt(const u16* xc, int M, const u16* wc, int N, int kc, co
         attr = true;
     }
     const int wgs = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN>), dim3(wgs), dim3(256), lds, s, xc, M, wc, N, kc, out, (long long)N, epi);
+    hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN>), dim3(wgs), dim3(256), lds, s, xc, M, wc, N, kc, out, ldo ? ldo : (long long)N, epi);
     NCX_HIP_TRY(hipGetLastError());
     return NCX_OK;
 }
@@ -337,11 +338,82 @@ int bf16_dw1c(const ncx_dims& d, const float* dpre, u16* dpre_bf, const u16* xc,
     const int nz = (M + chunk - 1) / chunk;
     const int tiles_m = Hp / BM, tiles_n = cc.kc / BN;
     hipLaunchKernelGGL((gemm_bf16_tn_kernel<BM, BN>), dim3(tiles_m * tiles_n * BF16_SPLIT), dim3(256), lds, s, (const u16*)dpre_bf, Hp,
-                       xc, cc.kc, M, chunk, tiles_m, slab, d.H, cc.kc);
+                       xc, cc.kc, M, chunk, tiles_m, BF16_SPLIT, slab, d.H, cc.kc);
     NCX_HIP_TRY(hipGetLastError());
     const long long n = (long long)d.H * cc.raw;
     hipLaunchKernelGGL(k_bf16_reduce_dwc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, cc, seg_offsets(d), (const float*)slab, nz,
                        g_w1, dgt);
+    NCX_HIP_TRY(hipGetLastError());
+    return NCX_OK;
+}
+
+// ---- the answer-embedding products of the bf16 variant ------------------------------------------------------------
+// dst[r][c] = bf16(src[r*ld + c]) for r < R, c < C; zero elsewhere in the [Rp][Cp] image
+__global__ __launch_bounds__(256) void k_pack2d(const float* __restrict__ src, long long ld, int R, int C, u16* __restrict__ dst, int Rp, int Cp) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)Rp * Cp) return;
+    const int r = (int)(i / Cp), c = (int)(i - (long long)r * Cp);
+    dst[i] = to_bf16(r < R && c < C ? src[(long long)r * ld + c] : 0.f);
+}
+// dst[c][r] = bf16(src[r][c]) (transposed image [C][Rp], zero for r >= R); 32x32 tiles through LDS, both sides coalesced
+__global__ __launch_bounds__(256) void k_pack_transposed(const float* __restrict__ src, int R, int C, u16* __restrict__ dst, int Rp) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < R && c < C) ? src[(long long)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        if (c < C && r < Rp) dst[(long long)c * Rp + r] = to_bf16(tile[tx][j]);
+    }
+}
+
+static int pack2d(const float* src, long long ld, int R, int C, u16* dst, int Rp, int Cp, hipStream_t s) {
+    const long long n = (long long)Rp * Cp;
+    hipLaunchKernelGGL(k_pack2d, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, ld, R, C, dst, Rp, Cp);
+    NCX_HIP_TRY(hipGetLastError());
+    return NCX_OK;
+}
+
+int bf16_pack_embedding(const ncx_dims& d, const float* E, const float* w1, const Bf16Emb& m, hipStream_t s) {
+    const SegOffsets o = seg_offsets(d);
+    int rc = pack2d(E, d.da, d.A, d.da, m.e_bf, d.A, m.dap, s); if (rc) return rc;                       // E       [A][dap]
+    hipLaunchKernelGGL(k_pack_transposed, dim3((unsigned)((d.da + 31) / 32), (unsigned)((m.Ap + 31) / 32)), dim3(256), 0, s,
+                       E, d.A, d.da, m.et_bf, m.Ap);                                                      // E^T     [da][Ap]
+    NCX_HIP_TRY(hipGetLastError());
+    rc = pack2d(w1 + o.a_other, o.din, d.H, d.da, m.w1a_bf, d.H, m.dap, s); if (rc) return rc;            // W1ak    [H][dap]
+    return pack2d(w1 + o.a_gt, o.din, d.H, d.da, m.w1a_bf + (long long)d.H * m.dap, d.H, m.dap, s);       // W1agt   [H][dap] (stacked below)
+}
+
+// Gt[H, A] = bf16(W1ak) . bf16(E)^T
+int bf16_gt(const ncx_dims& d, const Bf16Emb& m, float* gt, hipStream_t s) {
+    EpiArgs e{};
+    return launch_bf16_nt<64, 64>(m.w1a_bf, d.H, m.e_bf, d.A, m.dap, e, gt, s, d.A);
+}
+
+// dW1[:, a_other] = bf16(dGt) . bf16(E)
+int bf16_dw1ak(const ncx_dims& d, const Bf16Emb& m, const float* dgt_dagt, float* g_w1, hipStream_t s) {
+    const SegOffsets o = seg_offsets(d);
+    int rc = pack2d(dgt_dagt, d.A, 2 * d.H, d.A, m.dg_bf, 2 * d.H, m.Ap, s); if (rc) return rc;             // [dGt; dGgt]  [2H][Ap]
+    EpiArgs e{};
+    return launch_bf16_nt<64, 64>(m.dg_bf, d.H, m.et_bf, d.da, m.Ap, e, g_w1 + o.a_other, s, o.din);
+}
+
+// dE = bf16([dGt; dGgt])^T . bf16([W1ak; W1agt])   (one 2H-deep reduction instead of two chained H-deep ones)
+int bf16_de(const ncx_dims& d, const Bf16Emb& m, const float* dgt_dagt, float* g_E, hipStream_t s) {
+    int rc = pack2d(dgt_dagt, d.A, 2 * d.H, d.A, m.dg_bf, 2 * d.H, m.Ap, s); if (rc) return rc;
+    constexpr int BM = 128, BN = 128;
+    const int lds = 4 * 64 * TN_PITCH;
+    static bool attr = false;
+    if (!attr) {
+        NCX_HIP_TRY(hipFuncSetAttribute((const void*)gemm_bf16_tn_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    const int rows = 2 * d.H, tiles_m = m.Ap / BM, tiles_n = m.dap / BN;
+    hipLaunchKernelGGL((gemm_bf16_tn_kernel<BM, BN>), dim3(tiles_m * tiles_n), dim3(256), lds, s, (const u16*)m.dg_bf, m.Ap,
+                       (const u16*)m.w1a_bf, m.dap, rows, (rows + 63) / 64 * 64, tiles_m, 1, g_E, d.A, d.da);
     NCX_HIP_TRY(hipGetLastError());
     return NCX_OK;
 }

@@ -58,6 +58,7 @@ struct WsLayout {
     size_t slab_bytes;
     size_t slab2, slab2_bytes;          // slab of the GEMMs that run on the internal side stream
     size_t xc, wc, dpre_bf, bf_slab;    // NCX_F_BF16: packed bf16 candidate rows / weights / dpre, k-chunk slabs of dWc
+    size_t bf_emb;                      // NCX_F_BF16: bf16 images of E, E^T, [W1ak; W1agt], [dGt; dGgt]
     size_t total;
 };
 constexpr int NCX_COLSUM_CHUNKS = 256;
