@@ -44,9 +44,10 @@ extern "C" {
 #define NCX_F_A_EMB    (1u << 3)   /* answer embeddings (cx.py:279-282), else noise blocks          */
 #define NCX_F_ALL      (NCX_F_V_MULT | NCX_F_V_DIST | NCX_F_V_RANK | NCX_F_A_EMB)
 /* BASELINE configs[4] ("bf16 weights"; net-new, the reference is fp32 only): the two dominant GEMMs -- candidate
- * segments of linear_1 forward, and their weight gradient -- take bf16 operands (round-to-nearest-even copies of
- * the fp32 master weights, inputs and pre-activation gradients) with fp32 accumulation on the bf16 MFMA path;
- * everything else, including Adam on the fp32 master weights, is unchanged.  Needs NCX_F_ALL (no lesions). */
+ * segments of linear_1 forward, and their weight gradient -- and the three answer-embedding products (Gt forward,
+ * d linear_1.weight[:, a_emb_other] and d answer_embedding backward) take bf16 operands (round-to-nearest-even
+ * copies of the fp32 master weights, inputs and gradients) with fp32 accumulation on the bf16 MFMA path; everything
+ * else, including Adam on the fp32 master weights, is unchanged.  Needs NCX_F_ALL (no lesions). */
 #define NCX_F_BF16     (1u << 4)
 /* Evaluation loops (eval_model, counterexamples.py:450-490): Gt = W1[:, a_emb_other] . E^T depends on the weights only.
  * With this bit ncx_forward trusts the Gt left in the workspace by an earlier ncx_forward on the SAME workspace and
