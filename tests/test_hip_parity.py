@@ -172,6 +172,21 @@ def test_bf16_variant_vs_bf16_oracle(B, K, H, L, dv, strict):
     assert 1e-4 < float((s16 - s32).abs().max()) <= 0.3          # eval mode: bf16 operands vs the fp32 network
 
 
+def test_rows_wider_than_the_register_resident_prep_path():
+    """k_prep keeps rows of up to 2048 floats in registers (single pass); wider feature / answer rows take the re-reading
+    path.  Both must agree with the oracle (fp32 and the bf16 variant's row pack)."""
+    d = orc.Dims(dv=2100, dq=40, dz=12, A=2070, H=16, L=1)
+    params = orc.init_params(d, seed=2, gain=3.0)
+    batch = random_case(41, 3, d)
+    compare_with_oracle(d, None, params, batch)
+    scores, lr, grads = run_hip_bf16(d, params, batch)
+    s_ref, l_ref, g_ref = orc.loss_and_grads_bf16(params, d, batch)
+    assert np.abs(scores.numpy() - s_ref.numpy()).max() <= 5e-3
+    for k, ref in g_ref.items():
+        ref = ref.numpy()
+        assert np.abs(grads[k].reshape(ref.shape) - ref).max() <= 2e-3 * max(np.abs(ref).max(), GRAD_FLOOR), k
+
+
 def test_train_mode_explicit_masks_and_generator():
     d = orc.Dims(dv=64, dq=48, dz=16, A=20, H=32, L=3)
     params = orc.init_params(d, seed=5, gain=3.0)

@@ -39,10 +39,16 @@ __device__ __forceinline__ void store_bf16x4(u16* p, const float (&v)[4], int va
     else { for (int j = 0; j < valid; ++j) p[j] = f32_to_bf16(v[j]); }
 }
 
+// One wave per candidate row.  Rows of up to 2048 floats (the real widths: 2048-d features, 2000 answers) are read from
+// memory ONCE into registers (8 x float4 per lane) and every pass -- distance, max, sum, bf16 pack -- runs on the
+// registers; wider rows (RESIDENT = false) re-read them from memory per pass.  Same per-lane element order and the same
+// wave reductions either way, so the results do not depend on the path.
+template <bool RESIDENT>
 __global__ __launch_bounds__(256) void k_prep(ncx_dims d, ncx_inputs in, int* __restrict__ idx_k,
                                               int* __restrict__ idx_o, int* __restrict__ idx_ob,
                                               float* __restrict__ mx, float* __restrict__ inv,
                                               float* __restrict__ misc, u16* __restrict__ xc, Bf16Cols cc) {
+    constexpr int NR = RESIDENT ? 8 : 1;
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int M = d.B * d.K;
@@ -51,17 +57,37 @@ __global__ __launch_bounds__(256) void k_prep(ncx_dims d, ncx_inputs in, int* __
     const int io = in.img_idx[(long long)b * (d.K + 1)];
     const int ik = in.img_idx[(long long)b * (d.K + 1) + 1 + k];
     if (lane == 0) { idx_o[r] = io; idx_k[r] = ik; if (k == 0) idx_ob[b] = io; }
+    const float* vo = in.feats + (long long)io * d.dv;
+    const float* vk = in.feats + (long long)ik * d.dv;
+    u16* xr = xc ? xc + (long long)r * cc.kc : nullptr;
+    const bool need_v = (d.flags & NCX_F_V_DIST) || xc;
 
+    f32x4 ro[NR], rk[NR];
+    if (RESIDENT && need_v) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) { ro[i] = load4(vo, lane * 4 + 256 * i, d.dv); rk[i] = load4(vk, lane * 4 + 256 * i, d.dv); }
+    }
+    auto v_at = [&](int i, int c, f32x4& a, f32x4& e) __attribute__((always_inline)) {
+        if (RESIDENT) { a = ro[i]; e = rk[i]; } else { a = load4(vo, c, d.dv); e = load4(vk, c, d.dv); }
+    };
     float dist = 0.f;
     if (d.flags & NCX_F_V_DIST) {
-        const float* vo = in.feats + (long long)io * d.dv;
-        const float* vk = in.feats + (long long)ik * d.dv;
         float s = 0.f;
-        for (int c = lane * 4; c < d.dv; c += 256) {
-            const f32x4 a = load4(vo, c, d.dv), e = load4(vk, c, d.dv);
+        if (RESIDENT) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (c + j < d.dv) { const float t = a[j] - e[j] + 1e-6f; s += t * t; }
+            for (int i = 0; i < NR; ++i) {
+                const int c = lane * 4 + 256 * i;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < d.dv) { const float t = ro[i][j] - rk[i][j] + 1e-6f; s += t * t; }
+            }
+        } else {
+            for (int c = lane * 4; c < d.dv; c += 256) {
+                f32x4 a, e; v_at(0, c, a, e);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < d.dv) { const float t = a[j] - e[j] + 1e-6f; s += t * t; }
+            }
         }
         dist = sqrtf(wave_sum(s));
     }
@@ -70,48 +96,28 @@ __global__ __launch_bounds__(256) void k_prep(ncx_dims d, ncx_inputs in, int* __
     if (lane == 0) mrow[0] = dist;
     for (int j = lane; j < d.K; j += 64)
         mrow[1 + j] = (d.flags & NCX_F_V_RANK) ? (j == k ? 1.f : 0.f) : in.v_rank[((long long)r) * d.K + j];
-
-    if (d.flags & NCX_F_A_EMB) {
-        const float* a = in.a_knns + (long long)r * d.A;
-        float m = -INFINITY;
-        for (int c = lane * 4; c < d.A; c += 256) {
-            const f32x4 v = load4(a, c, d.A);
+    if (xc) {               // NCX_F_BF16: [ v_k | v_o * v_k | dist, rank | z_k | softmax (below) ], zero in the gaps
+        if (RESIDENT) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (c + j < d.A) m = fmaxf(m, v[j]);
-        }
-        m = wave_max(m);
-        float s = 0.f;
-        for (int c = lane * 4; c < d.A; c += 256) {
-            const f32x4 v = load4(a, c, d.A);
+            for (int i = 0; i < NR; ++i) {
+                const int c = lane * 4 + 256 * i;
+                if (c < cc.c_vm) {                                     // (segments are padded to multiples of 8 columns)
+                    float pk[4], pm[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (c + j < d.A) s += __expf(v[j] - m);
-        }
-        s = wave_sum(s);
-        // base-2 log-sum-exp: softmax(a)[c] = exp2(a[c]*log2e - lse2)
-        const float lse2 = m * 1.44269504088896341f + __log2f(s);
-        if (lane == 0) { mx[r] = lse2; inv[r] = 0.f; }
-        if (xc) {           // NCX_F_BF16: the softmax row itself, rounded to bf16, is the last segment of the packed row
-            u16* xp = xc + (long long)r * cc.kc + cc.c_p;
-            for (int c = lane * 4; c < d.A; c += 256) {
-                const f32x4 v = load4(a, c, d.A);
-                float e[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[j], 1.44269504088896341f, -lse2));
-                store_bf16x4(xp + c, e, d.A - c);
+                    for (int j = 0; j < 4; ++j) { pk[j] = rk[i][j]; pm[j] = ro[i][j] * rk[i][j]; }   // load4: zero beyond dv
+                    store_bf16x4(xr + cc.c_vk + c, pk, 4);
+                    store_bf16x4(xr + cc.c_vm + c, pm, 4);
+                }
             }
-        }
-    }
-    if (xc) {               // NCX_F_BF16: [ v_k | v_o * v_k | dist, rank | z_k | (softmax above) ], zero in the gaps
-        u16* xr = xc + (long long)r * cc.kc;
-        const float* vo = in.feats + (long long)io * d.dv;
-        const float* vk = in.feats + (long long)ik * d.dv;
-        for (int c = lane * 4; c < cc.c_vm; c += 256) {               // (segments are padded to multiples of 8 columns)
-            const f32x4 a = load4(vo, c, d.dv), e = load4(vk, c, d.dv);   // zero beyond dv
-            float pk[4], pm[4];
+        } else {
+            for (int c = lane * 4; c < cc.c_vm; c += 256) {
+                f32x4 a, e; v_at(0, c, a, e);
+                float pk[4], pm[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { pk[j] = e[j]; pm[j] = a[j] * e[j]; }
-            store_bf16x4(xr + cc.c_vk + c, pk, 4);
-            store_bf16x4(xr + cc.c_vm + c, pm, 4);
+                for (int j = 0; j < 4; ++j) { pk[j] = e[j]; pm[j] = a[j] * e[j]; }
+                store_bf16x4(xr + cc.c_vk + c, pk, 4);
+                store_bf16x4(xr + cc.c_vm + c, pm, 4);
+            }
         }
         for (int j = lane; j < cc.c_z - cc.c_misc; j += 64)
             xr[cc.c_misc + j] = f32_to_bf16(j == 0 ? dist : (j <= d.K && j - 1 == k ? 1.f : 0.f));
@@ -124,6 +130,69 @@ __global__ __launch_bounds__(256) void k_prep(ncx_dims d, ncx_inputs in, int* __
             store_bf16x4(xr + cc.c_z + c, pz, 4);
         }
         for (int c = cc.raw + lane; c < cc.kc; c += 64) xr[c] = 0;
+    }
+
+    if (d.flags & NCX_F_A_EMB) {
+        const float* a = in.a_knns + (long long)r * d.A;
+        f32x4 ra[NR];
+        if (RESIDENT) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) ra[i] = load4(a, lane * 4 + 256 * i, d.A);
+        }
+        float m = -INFINITY;
+        if (RESIDENT) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (lane * 4 + 256 * i + j < d.A) m = fmaxf(m, ra[i][j]);
+        } else {
+            for (int c = lane * 4; c < d.A; c += 256) {
+                const f32x4 v = load4(a, c, d.A);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (c + j < d.A) m = fmaxf(m, v[j]);
+            }
+        }
+        m = wave_max(m);
+        float s = 0.f;
+        if (RESIDENT) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (lane * 4 + 256 * i + j < d.A) s += __expf(ra[i][j] - m);
+        } else {
+            for (int c = lane * 4; c < d.A; c += 256) {
+                const f32x4 v = load4(a, c, d.A);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (c + j < d.A) s += __expf(v[j] - m);
+            }
+        }
+        s = wave_sum(s);
+        // base-2 log-sum-exp: softmax(a)[c] = exp2(a[c]*log2e - lse2)
+        const float lse2 = m * 1.44269504088896341f + __log2f(s);
+        if (lane == 0) { mx[r] = lse2; inv[r] = 0.f; }
+        if (xc) {           // NCX_F_BF16: the softmax row itself, rounded to bf16, is the last segment of the packed row
+            u16* xp = xr + cc.c_p;
+            if (RESIDENT) {
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    const int c = lane * 4 + 256 * i;
+                    if (c < d.A) {
+                        float e[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(ra[i][j], 1.44269504088896341f, -lse2));
+                        store_bf16x4(xp + c, e, d.A - c);
+                    }
+                }
+            } else {
+                for (int c = lane * 4; c < d.A; c += 256) {
+                    const f32x4 v = load4(a, c, d.A);
+                    float e[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[j], 1.44269504088896341f, -lse2));
+                    store_bf16x4(xp + c, e, d.A - c);
+                }
+            }
+        }
     }
 }
 
@@ -777,8 +846,12 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
     if (ss) { rc = side_fork(ss, s); if (rc) return rc; }
     const bool bf16 = d.flags & NCX_F_BF16;
     u16* xc = bf16 ? (u16*)(ws + w.xc) : nullptr;
-    hipLaunchKernelGGL(k_prep, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, s, d, *in, idx_k, idx_o, idx_ob, mx, inv, misc, xc,
-                       bf16_cols(d));
+    if (d.dv <= 2048 && d.A <= 2048)
+        hipLaunchKernelGGL(k_prep<true>, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, s, d, *in, idx_k, idx_o, idx_ob, mx, inv, misc, xc,
+                           bf16_cols(d));
+    else
+        hipLaunchKernelGGL(k_prep<false>, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, s, d, *in, idx_k, idx_o, idx_ob, mx, inv, misc, xc,
+                           bf16_cols(d));
     NCX_HIP_TRY(hipGetLastError());
 
     // Gt[H, A] = W1[:, a_other] . E^T   (weights only: evaluation passes reuse it, NCX_F_REUSE_GT)
