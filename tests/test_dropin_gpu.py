@@ -260,7 +260,7 @@ def test_cli_baseline_scorers(tmp_path, capsys):
     assert "BlackBox: 160 triplets" in capsys.readouterr().out
 
 
-def _dp_gpu_worker(rank, world, port, q):
+def _dp_gpu_worker(rank, world, port, q, bf16=False):
     import os, sys
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     from conftest import PKG, ROOT
@@ -274,7 +274,7 @@ def _dp_gpu_worker(rank, world, port, q):
     batch = _dp_batch(d, Bg)
     params = orc.init_params(d, seed=4, gain=2.0)
     eng = NeuralCXEngine(K=d.K, dv=d.dv, dq=d.dq, dz=d.dz, da=d.da, A=d.A, H=d.H, L=d.L, drop_p=0.0, lr=1e-3, device=DEV,
-                         world_size=world)
+                         world_size=world, bf16=bf16)
     eng.rank = rank
     eng.load_state(params)
     ids = dp.shard(list(range(Bg)), rank, world)
@@ -328,30 +328,34 @@ def test_eval_passes_reuse_gt_and_notice_weight_changes():
     assert torch.equal(s4, fresh.eval_step(to_batch(bt, slice(0, 12)), gt(bt, slice(0, 12)))["scores"])
 
 
-def test_dp2_hip_engine_equals_dp1():
+@pytest.mark.parametrize("bf16", [False, True])
+def test_dp2_hip_engine_equals_dp1(bf16):
     """SURVEY 8e: DP-R == DP-1 at the same global batch.  Two gloo ranks share the card (RCCL needs one GPU per rank);
-    each runs the HIP engine on its shard with loss_scale = 1/B_global, phased backward + async all-reduce, Adam."""
+    each runs the HIP engine on its shard with loss_scale = 1/B_global, phased backward + async all-reduce, Adam.
+    bf16: the configs[4] variant (its answer_embedding gradient comes from the bf16 image of the SUMMED dGt | dGgt block,
+    which is also what a single process computes for the global batch)."""
     import torch.multiprocessing as mp
     from neuralcx import ops
     from neuralcx.engine import NeuralCXEngine
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29700 + os.getpid() % 200
-    procs = [ctx.Process(target=_dp_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_gpu_worker, args=(r, 2, port + int(bf16), q, bf16)) for r in range(2)]
     [p.start() for p in procs]
     dp2 = q.get(timeout=240)
     [p.join(120) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     d = orc.Dims(dv=96, dq=64, dz=24, A=40, H=64, L=2)
     batch = _dp_batch(d, 12)
-    eng = NeuralCXEngine(K=d.K, dv=d.dv, dq=d.dq, dz=d.dz, da=d.da, A=d.A, H=d.H, L=d.L, drop_p=0.0, lr=1e-3, device=DEV)
+    eng = NeuralCXEngine(K=d.K, dv=d.dv, dq=d.dq, dz=d.dz, da=d.da, A=d.A, H=d.H, L=d.L, drop_p=0.0, lr=1e-3, device=DEV, bf16=bf16)
     eng.load_state(orc.init_params(d, seed=4, gain=2.0))
     b = ops.Batch.from_dense(*[batch[k].to(DEV) for k in ("image_features", "q_emb", "z_orig", "z_knns", "a_knns", "answer_aids")])
     r = eng.train_step(b, batch["gt"].to(DEV).to(torch.int32))
     assert abs(dp2.pop("__loss__") - float(r["loss"])) <= 1e-5
+    rel = 2e-3 if bf16 else 1e-5      # bf16: each rank rounds ITS rows' dpre to bf16 -- same values; dE sees bf16(sum) on both sides
     for k, v in eng.grads.views.items():
         ref = v.cpu().numpy()
-        assert np.abs(dp2[k] - ref).max() <= 1e-5 * max(np.abs(ref).max(), GRAD_FLOOR), k      # summation order only
+        assert np.abs(dp2[k] - ref).max() <= rel * max(np.abs(ref).max(), GRAD_FLOOR), k      # summation order only
 
 
 @pytest.mark.parametrize("name", ["g1_small_L1", "g1_small_H20_L2"])
