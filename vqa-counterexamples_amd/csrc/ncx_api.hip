@@ -557,6 +557,19 @@ enum { U_GT = 0, U_SH, U_MAIN, U_FWD_L, U_DW1C, U_DW1S, U_DE, U_DW1AK, U_DAGT, U
 
 static inline long long ks(long long k) { return cdiv(k, GEMM_BK); }
 
+// Split of one candidate-column problem of the grouped dW1 launch.  The big problems (2048 / 2000 columns) fill whole
+// rounds of workgroup slots; the narrow ones (dist + rank: 25 columns, z_other: 360) are dispatched after them and would
+// keep a few CUs busy for a full-length tail: they get twice as many, shorter k-chunks (still >= 8 k-steps each).
+static int dw1c_seg_split(long long cols, int S, long long ksteps) {
+    if (S <= 1 || cols > 512) return S;
+    int mult = 2;                     // measured at C2: x1 0.445-0.450 ms, x2 0.427, x3 0.438, x4 0.443
+    if (const char* e = hook_env("NCX_SMALL_MULT")) mult = atoi(e) > 0 ? atoi(e) : 1;
+    long long sp = (long long)S * mult;
+    const long long smax = ksteps / 8 > 1 ? ksteps / 8 : 1;
+    if (sp > smax) sp = smax;
+    return (int)(sp < S ? S : sp);
+}
+
 static void list_uses(const ncx_dims& d, GemmUse* u) {
     const long long M = (long long)d.B * d.K, H = d.H;
     const bool aemb = d.flags & NCX_F_A_EMB;
@@ -621,7 +634,7 @@ static void list_uses(const ncx_dims& d, GemmUse* u) {
         if (grouped) {
             const long long* sg = i == U_DW1C ? segs_c : segs_s;
             for (int q = 0; q < 5; ++q)
-                if (sg[q] > 0) wgs += WgMap{(int)cdiv(H, bm), (int)cdiv(sg[q], bn), S}.count();
+                if (sg[q] > 0) wgs += WgMap{(int)cdiv(H, bm), (int)cdiv(sg[q], bn), i == U_DW1C ? dw1c_seg_split(sg[q], S, u[i].ksteps) : S}.count();
         } else {
             wgs = WgMap{(int)cdiv(u[i].M, bm), (int)cdiv(u[i].N, bn), S}.count();
         }
@@ -1059,7 +1072,7 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
         int n = 0;
         auto add_c = [&](const XDesc& x, float* out, long long ldo) {
             a.a[n] = x_plain(dpre, H, M, H); a.b[n] = x; a.klen[n] = M; a.out[n] = out; a.ldo[n] = ldo; a.n_cols[n] = x.cols;
-            a.split[n] = u[U_DW1C].plan.split; ++n; };
+            a.split[n] = dw1c_seg_split(x.cols, u[U_DW1C].plan.split, u[U_DW1C].ksteps); ++n; };
         auto add_s = [&](const XDesc& x, float* out) {
             a.a[n] = x_plain(dsh, H, d.B, H); a.b[n] = x; a.klen[n] = d.B; a.out[n] = out; a.ldo[n] = din; a.n_cols[n] = x.cols;
             a.split[n] = u[U_DW1S].plan.split; ++n; };
@@ -1075,11 +1088,13 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
         if (want_rest && !bf16) {
             add_c(x_gather(in->feats, d.dv, idx_k, M, d.dv), g->w1 + o.v_other, din);
             if (d.flags & NCX_F_V_MULT) add_c(x_gather_mul(in->feats, d.dv, idx_k, idx_o, M, d.dv), g->w1 + o.v_mult, din);
-            add_c(x_plain(misc, d.K + 1, M, d.K + 1), g->w1 + o.v_dist, din);
-            add_c(x_plain(in->z_knns, d.dz, M, d.dz), g->w1 + o.z_other, din);
             if (!aemb) add_c(x_plain(in->a_knns, d.da, M, d.da), g->w1 + o.a_other, din);
         }
         if (want_dgt) add_c(x_softmax(in->a_knns, d.A, mx, inv, M, d.A), dgt, d.A);
+        if (want_rest && !bf16) {      // the narrow problems last among the candidate ones (shorter k-chunks: see dw1c_seg_split)
+            add_c(x_plain(in->z_knns, d.dz, M, d.dz), g->w1 + o.z_other, din);
+            add_c(x_plain(misc, d.K + 1, M, d.K + 1), g->w1 + o.v_dist, din);
+        }
         if (want_rest) {
             add_s(x_gather(in->feats, d.dv, idx_ob, d.B, d.dv), g->w1 + o.v_orig);
             add_s(x_plain(in->q_emb, d.dq, d.B, d.dq), g->w1 + o.q_emb);
