@@ -561,7 +561,9 @@ static inline long long ks(long long k) { return cdiv(k, GEMM_BK); }
 // rounds of workgroup slots; the narrow ones (dist + rank: 25 columns, z_other: 360) are dispatched after them and would
 // keep a few CUs busy for a full-length tail: they get twice as many, shorter k-chunks (still >= 8 k-steps each).
 static int dw1c_seg_split(long long cols, int S, long long ksteps) {
-    if (S <= 1 || cols > 512) return S;
+    long long narrow = 512;
+    if (const char* e = hook_env("NCX_SMALL_COLS")) narrow = atoll(e);
+    if (S <= 1 || cols > narrow) return S;
     int mult = 2;                     // measured at C2: x1 0.445-0.450 ms, x2 0.427, x3 0.438, x4 0.443
     if (const char* e = hook_env("NCX_SMALL_MULT")) mult = atoi(e) > 0 ? atoi(e) : 1;
     long long sp = (long long)S * mult;
