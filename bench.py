@@ -158,7 +158,7 @@ def main():
         r = step(i)
     fence()
     if rank == 0:
-        _lib.profile_begin(["MAIN", "DW1C"], max_launches=2 * args.steps + 8)
+        _lib.profile_begin(["MAIN", "DW1C"], max_launches=4 * args.steps + 8)
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -184,7 +184,8 @@ def main():
         d0 = eng._dims(pool[0][0], True, 1.0 / gb)
         plans = {k: _lib.plan_query(d0, k) for k in ("MAIN", "DW1C")}
         names = {"MAIN": "seg_gemm NT %s (linear_1 candidate segments, fwd)" % plans["MAIN"]["tile"],
-                 "DW1C": "seg_gemm TN %s grouped, %d-way aligned split-K (all linear_1 weight-grad columns + dGt, incl. fix-up)"
+                 "DW1C": "linear_1 weight gradient (all columns + dGt): k_dw_km (v_other + v_mult columns in one MFMA pass, per-triplet "
+                         "fold, 8 k-chunks) + seg_gemm TN %s grouped, %d-way aligned split-K (remaining columns), incl. reductions"
                          % (plans["DW1C"]["tile"], plans["DW1C"]["ksplit"])}
         peak = PEAK_F32_MFMA_TFLOPS
         if args.bf16:
@@ -193,7 +194,8 @@ def main():
                      "DW1C": "gemm_bf16_tn 128x128, 8 k-chunks (one per XCD) + dpre cast + reduce/scatter (all candidate weight-grad columns + dGt)"}
             for k in plans:
                 plans[k] = dict(plans[k], tile="bf16", ksplit=1 if k == "MAIN" else 8)
-        per = {k: sum(v) / len(v) for k, v in prof.items() if v}
+        # per STEP: the weight gradient of linear_1 is two launches under one id (fused v_other / v_mult kernel + grouped rest)
+        per = {k: sum(v) / args.steps for k, v in prof.items() if v}
         dom = max(per, key=per.get) if per else None
         roof = None
         if dom:

@@ -593,7 +593,8 @@ static void list_uses(const ncx_dims& d, GemmUse* u) {
     const bool hooks = experiment_hooks_on();
     for (int i = 0; i < U_COUNT; ++i) {
         // grouped launches (DW1C + DW1S): tiles are counted per column segment
-        const long long segs_c[5] = {d.dv, (d.flags & NCX_F_V_MULT) ? d.dv : 0, d.K + 1, d.dz, aemb ? d.A : d.da};
+        const bool km = dw_km_supported(d) && !(d.flags & NCX_F_BF16);     // v_other / v_mult columns: ncx_dwkm.hip
+        const long long segs_c[5] = {km ? 0 : d.dv, (!km && (d.flags & NCX_F_V_MULT)) ? d.dv : 0, d.K + 1, d.dz, aemb ? d.A : d.da};
         const long long segs_s[5] = {d.dv, d.dq, d.dz, d.da, 0};
         const bool grouped = i == U_DW1C || i == U_DW1S;
         auto grouped_tiles = [&](int bm, int bn) {
@@ -689,6 +690,7 @@ WsLayout ws_layout(const ncx_dims& d) {
         w.slab2_bytes = (size_t)s2 * 4;
         w.slab2 = take(w.slab2_bytes);
     }
+    w.km_slab = take(dw_km_slab_bytes(d));
     if (d.flags & NCX_F_BF16) {                          // packed bf16 operands of the two dominant GEMMs (ncx_bf16.h)
         w.xc = take(bf16_xc_bytes(d)); w.wc = take(bf16_wc_bytes(d));
         w.dpre_bf = take(bf16_dpre_bytes(d)); w.bf_slab = take(bf16_slab_bytes(d));
@@ -1087,9 +1089,18 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
             if (rc) return rc;
             rc = prof_close(U_DW1C, s); if (rc) return rc;
         }
-        if (want_rest && !bf16) {
+        const bool km = dw_km_supported(d) && !bf16;
+        if (want_rest && km) {      // v_other and v_mult columns in one MFMA pass (per-triplet fold)
+            rc = prof_open(U_DW1C, s); if (rc) return rc;
+            rc = dw_km(d, dpre, in->feats, idx_k, idx_o, (float*)(ws + w.km_slab), g->w1 + o.v_other, g->w1 + o.v_mult, din, s);
+            if (rc) return rc;
+            rc = prof_close(U_DW1C, s); if (rc) return rc;
+        }
+        if (want_rest && !bf16 && !km) {
             add_c(x_gather(in->feats, d.dv, idx_k, M, d.dv), g->w1 + o.v_other, din);
             if (d.flags & NCX_F_V_MULT) add_c(x_gather_mul(in->feats, d.dv, idx_k, idx_o, M, d.dv), g->w1 + o.v_mult, din);
+        }
+        if (want_rest && !bf16) {
             if (!aemb) add_c(x_plain(in->a_knns, d.da, M, d.da), g->w1 + o.a_other, din);
         }
         if (want_dgt) add_c(x_softmax(in->a_knns, d.A, mx, inv, M, d.A), dgt, d.A);

@@ -59,9 +59,17 @@ struct WsLayout {
     size_t slab2, slab2_bytes;          // slab of the GEMMs that run on the internal side stream
     size_t xc, wc, dpre_bf, bf_slab;    // NCX_F_BF16: packed bf16 candidate rows / weights / dpre, k-chunk slabs of dWc
     size_t bf_emb;                      // NCX_F_BF16: bf16 images of E, E^T, [W1ak; W1agt], [dGt; dGgt]
+    size_t km_slab;                     // k-chunk slabs of the fused v_other / v_mult weight gradient (ncx_dwkm.hip)
     size_t total;
 };
 constexpr int NCX_COLSUM_CHUNKS = 256;
+
+// ncx_dwkm.hip: d linear_1.weight[:, v_other] and [:, v_mult] in one MFMA pass with a per-triplet fold
+constexpr int DW_KM_SPLIT = 8;
+bool dw_km_supported(const ncx_dims& d);
+size_t dw_km_slab_bytes(const ncx_dims& d);
+int dw_km(const ncx_dims& d, const float* dpre, const float* feats, const int* idx_k, const int* idx_o, float* slab,
+          float* g_vother, float* g_vmult, long long din, hipStream_t s);
 WsLayout ws_layout(const ncx_dims& d);
 
 }  // namespace ncx
