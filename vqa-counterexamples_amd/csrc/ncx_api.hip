@@ -612,6 +612,7 @@ static void list_uses(const ncx_dims& d, GemmUse* u) {
                 const long long slots = (long long)occupancy_tn(CFG_128x64) * num_cus();
                 long long sp = cdiv(3 * slots, grouped_tiles(128, 64));
                 const long long smax = u[i].ksteps / 24 > 1 ? u[i].ksteps / 24 : 1;
+                if (sp > 8) sp = 8;          // one k-chunk per XCD at most (measured with the fused v-column kernel: x8 0.346, x12 0.354, x16 0.363 ms)
                 u[i].plan.split = (int)(sp > smax ? smax : sp < 1 ? 1 : sp);
             }
         } else {
