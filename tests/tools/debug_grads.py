@@ -1,6 +1,6 @@
 """Debug aid (GPU box): per-parameter / per-segment gradient error of the HIP path vs the oracle."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "vqa-counterexamples_amd"), os.path.join(ROOT, "tests")]
 import numpy as np, torch
 from oracle import ncx_oracle as orc
