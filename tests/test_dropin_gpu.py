@@ -71,6 +71,34 @@ def test_neuralmodel_module_forward_and_autograd(L):
             assert float((p.detach().cpu() - new[n]).abs()[big].max()) <= 2e-6, n
 
 
+@pytest.mark.parametrize("off", [("v_emb",), ("q_emb",), ("z_emb",), ("v_rank",), ("a_emb",), ("v_mult", "v_dist"), ("q_emb", "z_emb", "a_emb")])
+def test_neuralmodel_lesion_specs_run_like_the_reference(off):
+    """model_spec lesions (cx.py:265-307): noise-substituted segments (v_emb, q_emb, z_emb, v_rank, a_emb) and zeroed ones
+    (v_mult, v_dist) go through the module's forward / backward; noise lesions are reproducible under torch.manual_seed."""
+    import vqa.models as M
+    from vqa.models.cx import NeuralModel
+    A, B = 20, 4
+    torch.manual_seed(1)
+    vqa = M.factory(_tiny_opt(), ["w%d" % i for i in range(30)], ["a%d" % i for i in range(A)], cuda=True, data_parallel=False)
+    spec = dict(v_emb=True, v_mult=True, v_dist=True, v_rank=True, q_emb=True, a_emb=True, z_emb=True)
+    for k in off:
+        spec[k] = False
+    m = NeuralModel(model_spec=spec, dim_h=16, n_layers=2, emb=None, drop_p=0.25, vqa_model=vqa, knn_size=24, trainable_vqa=False).cuda()
+    m.eval()
+    feats = (torch.randn(B, 25, 64).abs() * 0.45).to(DEV)
+    wids = torch.randint(1, 31, (B, 26)).to(DEV)
+    aids = torch.randint(0, A, (B,)).to(DEV)
+    torch.manual_seed(7); s1 = m(feats, wids, aids)
+    torch.manual_seed(7); s2 = m(feats, wids, aids)
+    assert s1.shape == (B, 24) and torch.isfinite(s1).all() and torch.equal(s1, s2)
+    loss = torch.nn.CrossEntropyLoss(reduction="sum")(s1, torch.randint(0, 24, (B,)).to(DEV)) / B
+    loss.backward()
+    assert torch.isfinite(m.linear_1.weight.grad).all() and float(m.linear_1.weight.grad.abs().sum()) > 0
+    o = 3 * 64                                                       # v_orig | v_other | v_mult | v_dist | v_rank ...
+    if "v_mult" in off:
+        assert float(m.linear_1.weight.grad[:, 2 * 64:3 * 64].abs().max()) == 0.0 and float(m.linear_1.weight.grad[:, o].abs().max()) == 0.0
+
+
 def test_engine_training_matches_oracle_training():
     """30 Adam steps with dropout (shared counter-based masks) on identical synthetic data: per-step loss within
     1e-4 of the CPU oracle's training run, and Recall@1/@5 on held-out triplets identical (+-0.1 pt allowed)."""
