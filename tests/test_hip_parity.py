@@ -187,6 +187,19 @@ def test_rows_wider_than_the_register_resident_prep_path():
         assert np.abs(grads[k].reshape(ref.shape) - ref).max() <= 2e-3 * max(np.abs(ref).max(), GRAD_FLOOR), k
 
 
+@pytest.mark.parametrize("B,K,H,L,dv", [(1, 24, 16, 1, 70), (7, 24, 20, 2, 64), (13, 48, 48, 1, 130), (40, 24, 200, 1, 96), (9, 48, 132, 3, 2048)])
+def test_fused_v_gradient_kernel_vs_oracle(B, K, H, L, dv, monkeypatch):
+    """k_dw_km (d linear_1.weight[:, v_other] and [:, v_mult] in one MFMA pass with the per-triplet fold) is used from 256
+    triplets on; forced here on small / ragged shapes (edge tiles in both directions, K = 24 and 48, chunks with a single
+    triplet, empty chunks) and compared with the oracle like every other path."""
+    monkeypatch.setenv("NCX_EXPERIMENT", "1")
+    monkeypatch.setenv("NCX_KM_FORCE", "1")
+    d = orc.Dims(K=K, dv=dv, dq=50, dz=18, A=45, H=H, L=L)
+    params = orc.init_params(d, seed=23 + B, gain=3.0)
+    batch = random_case(700 + B, B, d)
+    compare_with_oracle(d, None, params, batch)
+
+
 def test_train_mode_explicit_masks_and_generator():
     d = orc.Dims(dv=64, dq=48, dz=16, A=20, H=32, L=3)
     params = orc.init_params(d, seed=5, gain=3.0)

@@ -179,13 +179,16 @@ __global__ __launch_bounds__(256) void k_dw_km_reduce(const float* __restrict__ 
 bool dw_km_supported(const ncx_dims& d) {
     // candidates per triplet a multiple of 24 (the reference's knn_size 24, configs[4]'s 48: two 24-row steps per triplet);
     // rows need 4 columns for the 16-byte windows
-    return (d.flags & NCX_F_V_MULT) && d.K % 24 == 0 && d.H >= 4 && d.dv >= 4;
+    // ... and at least 256 triplets: below that the step is a latency chain and the grouped GEMM path measured faster
+    // (B = 32 / 64 / 128: 0.489 / 0.493 / 0.553 ms against 0.52 / 0.53 / 0.58 with this kernel)
+    return (d.flags & NCX_F_V_MULT) && d.K % 24 == 0 && d.H >= 4 && d.dv >= 4 && (d.B >= 256 || hook_env("NCX_KM_FORCE"));
 }
 size_t dw_km_slab_bytes(const ncx_dims& d) { return dw_km_supported(d) ? (size_t)DW_KM_SPLIT * 2 * d.H * d.dv * 4 : 0; }
 
 int dw_km(const ncx_dims& d, const float* dpre, const float* feats, const int* idx_k, const int* idx_o, float* slab,
           float* g_vother, float* g_vmult, long long din, hipStream_t s) {
-    const int S = DW_KM_SPLIT;
+    // up to 8 k-chunks (one per XCD), at least 16 triplets each: tiny batches are not worth 8 partial tiles
+    const int S = d.B / 16 >= DW_KM_SPLIT ? DW_KM_SPLIT : (d.B / 16 >= 1 ? d.B / 16 : 1);
     const int chunk = (d.B + S - 1) / S, nz = (d.B + chunk - 1) / chunk;
     const int tiles_m = (d.H + KM_BM - 1) / KM_BM, tiles_n = (d.dv + KM_BN - 1) / KM_BN;
     constexpr int R = 24;
