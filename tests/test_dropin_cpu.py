@@ -149,6 +149,78 @@ def test_dp2_gloo_matches_single_process_gradient():
     assert np.abs(flat - ref).max() <= 1e-6 * max(np.abs(ref).max(), 1.0)
 
 
+def _dp_block_worker(rank, world, port, q):
+    """The engine's exchange (neuralcx/engine.py, backward phases 3 | 4) restated with torch on the CPU: every rank
+    all-reduces the 2 x [H, A] block dGt | dGgt and every gradient EXCEPT answer_embedding's, then computes the complete
+    embedding gradient dE = dGt^T . W1ak + dGgt^T . W1agt itself from the summed block."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path[:0] = [ROOT, PKG, os.path.join(ROOT, "tests")]
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    from neuralcx import dp
+    from helpers import load_golden
+    dp.init_distributed(backend="gloo")
+    g, d, spec, params, batch = load_golden("g1_small_L2")
+    B, K = batch["gt"].shape[0], d.K
+    ids = dp.shard(list(range(B)), rank, world)
+    sub = {k: v[ids] for k, v in batch.items()}
+    Bl = len(ids)
+    leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    W1, E = leaf["linear_1.weight"], leaf["answer_embedding.weight"]
+    o, c = {}, 0
+    for name, n in (("v_orig", d.dv), ("v_other", d.dv), ("v_mult", d.dv), ("v_dist", 1), ("v_rank", K), ("q_emb", d.dq),
+                    ("z_orig", d.dz), ("z_other", d.dz), ("a_gt", d.da), ("a_other", d.da)):
+        o[name] = (c, c + n); c += n
+    cols = lambda n: W1[:, o[n][0]:o[n][1]]
+    feats, aid = sub["image_features"], sub["answer_aids"]
+    v_o, v_k = feats[:, 0], feats[:, 1:]
+    # E enters only through these two products; detach it there so that its gradient is NOT produced by autograd
+    w1ak, w1agt = cols("a_other"), cols("a_gt")
+    gt_mat = w1ak @ E.detach().t(); gt_mat.retain_grad()
+    sh_a = F.embedding(aid, E.detach()) @ w1agt.t(); sh_a.retain_grad()
+    shared = torch.cat((v_o, sub["q_emb"], sub["z_orig"]), 1) @ torch.cat((cols("v_orig"), cols("q_emb"), cols("z_orig")), 1).t() \
+        + leaf["linear_1.bias"] + sh_a
+    dist_col = (v_o[:, None, :] - v_k + 1e-6).norm(dim=2, keepdim=True)
+    rank1h = torch.eye(K).view(1, K, K).expand(Bl, K, K)
+    xc = torch.cat((v_k, v_o[:, None, :] * v_k, dist_col, rank1h, sub["z_knns"], F.softmax(sub["a_knns"], dim=-1)), 2).reshape(Bl * K, -1)
+    wc = torch.cat((cols("v_other"), cols("v_mult"), cols("v_dist"), cols("v_rank"), cols("z_other"), gt_mat), 1)
+    h = F.relu(shared.repeat_interleave(K, 0) + xc @ wc.t())
+    h = F.relu(F.linear(h, leaf["linear_2.weight"], leaf["linear_2.bias"]))
+    scores = F.linear(h, leaf["out.weight"], leaf["out.bias"]).view(Bl, K)
+    loss = F.cross_entropy(scores, sub["gt"], reduction="sum") / B          # 1 / B_global
+    loss.backward()
+    block = torch.stack((gt_mat.grad, torch.zeros(d.H, d.A).index_add_(1, aid, sh_a.grad.t().contiguous())))   # dGt | dGgt
+    rest = [n for n in leaf if n != "answer_embedding.weight"]
+    flat = torch.cat([leaf[n].grad.reshape(-1) for n in rest])
+    h1 = dist.all_reduce(block, async_op=True)
+    h2 = dist.all_reduce(flat, async_op=True)
+    h1.wait()
+    dE = block[0].t() @ w1ak.detach() + block[1].t() @ w1agt.detach()     # "phase 4", while bucket 2 is in flight
+    h2.wait()
+    if rank == 0:
+        q.put((dE.numpy(), flat.numpy(), rest))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_dp2_block_exchange_reproduces_the_global_gradient():
+    """SURVEY 8e on the CPU (gloo, world size 2): summing dGt | dGgt instead of the embedding gradient, and recomputing the
+    latter on every rank, gives the golden single-process gradient of the global batch."""
+    from helpers import load_golden
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_block_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    dE, flat, rest = q.get(timeout=120)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    g, d, spec, params, batch = load_golden("g1_small_L2")
+    refE = g["grad/answer_embedding.weight"]
+    assert np.abs(dE - refE).max() <= 1e-5 * max(np.abs(refE).max(), 1e-2)
+    ref = np.concatenate([g["grad/" + k].reshape(-1) for k in rest])
+    assert np.abs(flat - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1.0)
+
+
 def test_examples_to_arrays_matches_reference_semantics():
     """getDataFromBatch (counterexamples.py:519-547): indices of [image] + knns, wids, aids, comp knn_index."""
     import random
