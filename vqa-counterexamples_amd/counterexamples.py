@@ -97,6 +97,7 @@ class Runner:
         self.rank, self.world, self.local = dp.init_distributed()
         if not torch.cuda.is_available():
             raise SystemExit("counterexamples.py: an MI355X is required (the HIP path has no CPU fallback)")
+        self.local %= max(1, torch.cuda.device_count())          # (rehearsals of several ranks on one card)
         torch.cuda.set_device(self.local)
         self.dev = torch.device("cuda", self.local)
         random.seed(42); torch.manual_seed(42); torch.cuda.manual_seed(42)          # counterexamples.py:119-121

@@ -23,8 +23,8 @@ def init_distributed(device_index: Optional[int] = None, backend: Optional[str] 
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:             # NCX_DIST_BACKEND=gloo: rehearsal of several ranks on one card
+            backend = os.environ.get("NCX_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", local if device_index is None else device_index)
