@@ -121,6 +121,7 @@ def main():
     from neuralcx.synth import SyntheticCX
 
     eng = NeuralCXEngine(K=args.K, H=args.H, L=args.L, drop_p=0.25, lr=1e-4, device=dev, world_size=world, bf16=args.bf16)
+    eng.rank = rank                                   # (per-rank dropout streams)
     eng.init_parameters(seed=42)                      # identical replicas on every rank
     data = SyntheticCX(n_triplets=args.batch * args.pool * world, K=args.K, n_img=args.n_img, seed=1234, device=dev)
     pool = []
