@@ -504,7 +504,7 @@ int num_cus() {
 // Measured (DW1C on 512 slots, 412 tiles x 384 k-steps): S = 4/5/6/7/9/12/16/24/32 -> 0.541/0.538/0.521/0.513/
 // 0.486/0.486/0.486/0.508/0.525 ms: aim for >= 6 rounds of workgroups but keep >= 24 k-steps in each.
 static int choose_split(long long tiles, long long ksteps, long long slots) {
-    if (tiles >= 4 * slots) return 1;
+    if (tiles >= slots) return 1;                  // at least one full round of workgroups already (dE at H=1024: 217 us unsplit, 230 us x2)
     long long sp = cdiv(6 * slots, tiles);
     const long long smax = ksteps / 24 > 1 ? ksteps / 24 : 1;
     if (sp > smax) sp = smax;
@@ -519,7 +519,11 @@ static int choose_split(long long tiles, long long ksteps, long long slots) {
 // tiles_small: output tiles with 64x64 blocks; ksteps: 32-deep reduction steps per tile.
 static GemmPlan plan_from_tiles(int form, long long tiles_big, long long tiles_small, long long ksteps, bool big_ok) {
     GemmPlan p; p.split = 1;
-    if (big_ok && tiles_big >= 192 && ksteps >= 64) { p.cfg = CFG_128x128; return p; }
+    // 128x128 tiles run one workgroup per CU: only when they fill whole rounds of CUs reasonably (dE at H=1024: 304 tiles =
+    // 1.19 rounds took 362 us, the 64x64 plan 217 us)
+    const long long cus = num_cus();
+    const double eff_big = (double)tiles_big / (double)(cdiv(tiles_big, cus) * cus);
+    if (big_ok && tiles_big >= 192 && ksteps >= 64 && eff_big >= 0.75) { p.cfg = CFG_128x128; return p; }
     // Measured on MI355X (DW1C, 412 small tiles x 384 k-steps): every TN tile shape (64x64, 128x64, 128x128) ends
     // at 0.45-0.51 ms; the 64x64 tile fits 3 workgroups per CU and is used for all split problems.
     p.cfg = CFG_64x64;
