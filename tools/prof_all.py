@@ -29,6 +29,7 @@ for n in names:
         per_step = sum(prof[n]) / a.steps
         tot += per_step
         pl = _lib.plan_query(d0, n)
-        print("%-6s %7.1f us/step (%d launches/step)  %s %dx%dx%d ksteps  tile %s split %d" % (
-            n, per_step * 1e3, len(prof[n]) // a.steps, pl["form"], pl["M"], pl["N"], pl["ksteps"], pl["tile"], pl["ksplit"]))
+        tf = 2.0 * pl["M"] * pl["N"] * pl["ksteps"] * 32 / (per_step * 1e-3) / 1e12      # (padded k: upper bound of the useful rate)
+        print("%-6s %7.1f us/step (%d launches/step)  %s %dx%dx%d ksteps  ~%.0fTF  tile %s split %d" % (
+            n, per_step * 1e3, len(prof[n]) // a.steps, pl["form"], pl["M"], pl["N"], pl["ksteps"], tf, pl["tile"], pl["ksplit"]))
 print("gemms %.1f us  step %.1f us" % (tot * 1e3, ev0.elapsed_time(ev1) / a.steps * 1e3))
