@@ -121,7 +121,8 @@ def forward_faithful(params: Dict[str, torch.Tensor], d: Dims,
                      drop_p: float = 0.0,
                      keep_masks: Optional[Sequence[torch.Tensor]] = None,
                      a_emb_gt_override: Optional[torch.Tensor] = None,
-                     v_rank_override: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     v_rank_override: Optional[torch.Tensor] = None,
+                     taps: Optional[dict] = None) -> torch.Tensor:
     """scores[B,K].  Follows vqa/models/cx.py:261-333 line by line: a Python loop over the
     K candidates, ``torch.cat`` of the ten segments, ``F.linear`` + relu (+ dropout) per
     hidden layer, ``out``.  ``keep_masks`` = None means eval mode (dropout is identity).
@@ -130,6 +131,7 @@ def forward_faithful(params: Dict[str, torch.Tensor], d: Dims,
     supplied by the caller as ordinary inputs (``a_knns`` then holds the [B,K,da] noise block,
     ``a_emb_gt_override`` the [B,da] one, ``v_rank_override`` [B,K,K] the per-candidate rank
     noise); zero-lesions (v_mult, v_dist) are handled here.
+    ``taps`` (tests only): receives ``pre1`` [B,K,H], the pre-activations of linear_1, and ``dist`` [B,K].
     """
     spec = dict(DEFAULT_SPEC, **(spec or {}))
     B = image_features.shape[0]
@@ -166,11 +168,18 @@ def forward_faithful(params: Dict[str, torch.Tensor], d: Dims,
                        a_emb_gt, a_emb_other), dim=1)               # cx.py:309-320
         h = x
         for l in range(1, d.L + 1):                                 # cx.py:322-326
-            h = F.relu(F.linear(h, params[f"linear_{l}.weight"], params[f"linear_{l}.bias"]))
+            pre = F.linear(h, params[f"linear_{l}.weight"], params[f"linear_{l}.bias"])
+            if taps is not None and l == 1:
+                taps.setdefault("pre1", []).append(pre.detach())
+                taps.setdefault("dist", []).append(v_dist.detach()[:, 0])
+            h = F.relu(pre)
             if keep_masks is not None:
                 m = keep_masks[l - 1].view(B, d.K, d.H)[:, i]
                 h = h * m / (1.0 - drop_p)
         scores.append(F.linear(h, params["out.weight"], params["out.bias"]))   # cx.py:327
+    if taps is not None:
+        taps["pre1"] = torch.stack(taps["pre1"], dim=1)
+        taps["dist"] = torch.stack(taps["dist"], dim=1)
     return torch.cat(scores, dim=1)                                 # cx.py:331
 
 
@@ -231,7 +240,8 @@ class _SharedAnswerEmbedding(torch.autograd.Function):
 
 
 def forward_bf16(params: Dict[str, torch.Tensor], d: Dims, image_features, q_emb, z_orig, z_knns, a_knns, answer_aids,
-                 drop_p: float = 0.0, keep_masks: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+                 drop_p: float = 0.0, keep_masks: Optional[Sequence[torch.Tensor]] = None,
+                 taps: Optional[dict] = None) -> torch.Tensor:
     """scores[B,K] of the NCX_F_BF16 variant: the same network as forward_faithful (vqa/models/cx.py:261-333) in its
     segmented form -- the four per-triplet segments in fp32; Gt = W1[:, a_emb_other] . E^T and the five per-candidate
     segments [v_k | v_o*v_k | dist, rank | z_k | softmax(a_k)] against [W1 slices | Gt] with BOTH operands rounded to
@@ -252,7 +262,11 @@ def forward_bf16(params: Dict[str, torch.Tensor], d: Dims, image_features, q_emb
     rank = torch.eye(K).view(1, K, K).expand(B, K, K)                                       # cx.py:304-305
     xc = torch.cat((v_k, v_o[:, None, :] * v_k, dist, rank, z_knns, F.softmax(a_knns, dim=-1)), 2).reshape(B * K, -1)
     wc = torch.cat((cols("v_other"), cols("v_mult"), cols("v_dist"), cols("v_rank"), cols("z_other"), gt_mat), 1)
-    h = F.relu(shared.repeat_interleave(K, 0) + _Bf16Product.apply(xc, wc))
+    pre = shared.repeat_interleave(K, 0) + _Bf16Product.apply(xc, wc)
+    if taps is not None:
+        taps["pre1"] = pre.detach().view(B, K, d.H)
+        taps["dist"] = dist.detach()[:, :, 0]
+    h = F.relu(pre)
     if keep_masks is not None:
         h = h * keep_masks[0].view(B * K, d.H) / (1.0 - drop_p)
     for l in range(2, d.L + 1):

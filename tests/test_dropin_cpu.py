@@ -216,7 +216,7 @@ def test_dp2_block_exchange_reproduces_the_global_gradient():
     assert all(p.exitcode == 0 for p in procs)
     g, d, spec, params, batch = load_golden("g1_small_L2")
     refE = g["grad/answer_embedding.weight"]
-    assert np.abs(dE - refE).max() <= 1e-5 * max(np.abs(refE).max(), 1e-2)
+    assert np.abs(dE - refE).max() <= 1e-4 * np.abs(refE).max()          # SURVEY 8c, no floor
     ref = np.concatenate([g["grad/" + k].reshape(-1) for k in rest])
     assert np.abs(flat - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1.0)
 
@@ -247,3 +247,93 @@ def test_examples_to_arrays_matches_reference_semantics():
         assert pidx[i, 1] == n2i[ex["knns"][ex["comp"]["knn_index"]]] and pidx[i, 2] != pidx[i, 1]
     b = batchify(list(range(10)), 4, shuffle=False)
     assert b == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]]
+
+
+def test_epoch_plan_gives_every_rank_an_entry_for_every_batch():
+    """batchify keeps the partial last batch (counterexamples.py:513-515): with 1027 examples, global batch 512 and 4
+    ranks the last batch has 3 triplets.  Every rank must still get an entry for it (a zero-weight padding triplet), the
+    active slices must tile each global batch exactly once, and plans must have equal length on every rank."""
+    from neuralcx import dp
+    for n, gb, world in ((1027, 512, 4), (5, 4, 3), (16385, 512, 8), (7, 8, 8), (24, 8, 2)):
+        plans = [dp.epoch_plan(n, gb, 1, r, world, "cpu", seed=42) for r in range(world)]
+        batches = dp.epoch_batches(n, gb, 1, seed=42)
+        assert all(len(p[1]) == len(batches) for p in plans)
+        for bi, b in enumerate(batches):
+            got = []
+            for ids, plan in plans:
+                lo, hi, ng, first, active = plan[bi]
+                assert ng == len(b) and hi > lo and int(ids[lo]) == first          # never an empty slice
+                if active:
+                    got += ids[lo:hi].tolist()
+                else:
+                    assert hi - lo == 1 and first == b[0]
+            assert got == b                                                         # tiled exactly once, in order
+        assert any(not e[4] for _, p in plans for e in p) == (n % gb != 0 and n % gb < world)
+
+
+def _dp3_worker(rank, world, port, q):
+    """The train loop's collective structure (counterexamples.py Runner.run_epoch + engine.train_step) with the oracle
+    as the per-rank engine: per plan entry ONE gradient all-reduce and, every print_freq steps, ONE metric reduction."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path[:0] = [ROOT, PKG, os.path.join(ROOT, "tests")]
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    from neuralcx import dp
+    from helpers import load_golden
+    from oracle import ncx_oracle as orc
+    dp.init_distributed(backend="gloo")
+    g, d, spec, params, batch = load_golden("g1_small_L1")
+    N, gb = 5, 4                                     # batches of 4 and 1: the last one is shorter than the world (3)
+    ids, plan = dp.epoch_plan(N, gb, 1, rank, world, "cpu", seed=42, shuffle=False)
+    n_coll, last = 0, None
+    for bi, (lo, hi, n_global, first, active) in enumerate(plan):
+        sel = ids[lo:hi]
+        leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        sub = {k: v[sel] for k, v in batch.items()}
+        scores = orc.forward_faithful(leaf, d, sub["image_features"], sub["q_emb"], sub["z_orig"], sub["z_knns"], sub["a_knns"],
+                                      sub["answer_aids"], spec=spec)
+        loss = F.cross_entropy(scores, sub["gt"], reduction="sum") * ((1.0 / n_global) if active else 0.0)
+        loss.backward()
+        flat = torch.cat([leaf[k].grad.reshape(-1) for k in params])
+        dist.all_reduce(flat); n_coll += 1           # engine.train_step: never skipped
+        dp.reduce_metrics(float(loss), 0, 0, int(hi - lo) if active else 0, "cpu"); n_coll += 1
+        last = flat
+    counts = torch.tensor([n_coll]); gathered = [torch.zeros_like(counts) for _ in range(world)]
+    dist.all_gather(gathered, counts)
+    if rank == 0:
+        q.put((last.numpy(), [int(c) for c in gathered]))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_dp3_short_last_batch_does_not_deadlock_and_matches_single_process():
+    """VERDICT r1 weak #5 / ADVICE: a global batch with fewer triplets than ranks used to make the empty-slice ranks skip
+    the step's collectives (hang).  World size 3 over gloo, last batch of ONE triplet: the run finishes, every rank entered
+    the same number of collectives, and the summed gradient of that batch equals the single-process gradient."""
+    from helpers import load_golden
+    from oracle import ncx_oracle as orc
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp3_worker, args=(r, 3, port, q)) for r in range(3)]
+    [p.start() for p in procs]
+    flat, counts = q.get(timeout=180)                 # (a hang shows up here)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert counts == [4, 4, 4]
+    g, d, spec, params, batch = load_golden("g1_small_L1")
+    sub = {k: v[4:5] for k, v in batch.items()}
+    _, _, g_ref = orc.loss_and_grads(params, d, sub, spec=spec)
+    ref = np.concatenate([g_ref[k].numpy().reshape(-1) for k in params])
+    assert np.abs(flat - ref).max() <= 1e-6 * np.abs(ref).max()
+
+
+def test_answer_aid_range_is_checked_when_the_data_enters():
+    from neuralcx.formats import examples_to_index_arrays
+    names = ["i%d" % i for i in range(30)]
+    n2i = {n: i for i, n in enumerate(names)}
+    ex = dict(image_name=names[0], knns=names[1:25], comp=dict(knn_index=3), question_wids=[1, 2, 0], answer_aid=2000)
+    examples_to_index_arrays([ex], n2i, 24)                       # unchecked without a vocabulary size
+    with pytest.raises(IndexError):
+        examples_to_index_arrays([ex], n2i, 24, n_answers=2000)
+    ex["answer_aid"] = 1999
+    assert examples_to_index_arrays([ex], n2i, 24, n_answers=2000)[2][0] == 1999

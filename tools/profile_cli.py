@@ -18,7 +18,7 @@ stages = {"ids": 0.0, "batch": 0.0, "step": 0.0, "acc": 0.0}
 acc = torch.zeros(3, dtype=torch.float64, device=r.dev)
 n = 0
 ids_dev, plan = dp.epoch_plan(r.train.N, r.gb, 2, 0, 1, r.dev, seed=42)
-for lo, hi, ng, first in plan:
+for lo, hi, ng, first, _active in plan:
     t = time.perf_counter(); it = ids_dev[lo:hi]; stages["ids"] += time.perf_counter() - t
     t = time.perf_counter(); b, gt = r.get_batch(r.train, it, first); torch.cuda.synchronize(); stages["batch"] += time.perf_counter() - t
     t = time.perf_counter(); res = r.engine.train_step(b, gt, global_batch=ng); torch.cuda.synchronize(); stages["step"] += time.perf_counter() - t

@@ -203,14 +203,14 @@ class Runner:
         ids, plan = dp.epoch_plan(tr.N, self.gb, epoch, self.rank, self.world, self.dev, seed=42)   # one H2D copy per epoch
         t0 = time.time(); seen = 0
         acc = torch.zeros(3, dtype=torch.float64, device=self.dev)        # loss*B_local, hits5, count (no host sync)
-        for bi, (lo, hi, n_global, first_id) in enumerate(plan):
+        for bi, (lo, hi, n_global, first_id, active) in enumerate(plan):
             if 0 <= self.args.max_steps <= bi:
                 break
-            if hi <= lo:
-                continue
+            # (a rank with an empty slice of a short last batch runs a zero-weight padding triplet: every rank enters
+            #  every collective below -- dp.epoch_plan)
             b, gt = self.get_batch(tr, ids[lo:hi], first_id)
-            r = eng.train_step(b, gt, global_batch=n_global)
-            acc[0] += r["loss"][0].double() * n_global; acc[1] += r["hits"][1].double(); acc[2] += hi - lo
+            r = eng.train_step(b, gt, global_batch=n_global, active=active)
+            acc[0] += r["loss"][0].double() * n_global; acc[1] += r["hits"][1].double(); acc[2] += (hi - lo) if active else 0
             seen += n_global
             if (bi + 1) % self.args.print_freq == 0:
                 l, _, h5, n = dp.reduce_metrics(float(acc[0]), 0, int(acc[1]), int(acc[2]), self.dev)
@@ -228,8 +228,8 @@ class Runner:
         eng = self.engine
         tot = torch.zeros(4, dtype=torch.float64, device=self.dev)
         ids, plan = dp.epoch_plan(data.N, self.gb, 0, self.rank, self.world, self.dev, shuffle=False)
-        for lo, hi, n_global, first_id in plan:
-            if hi <= lo:
+        for lo, hi, n_global, first_id, active in plan:
+            if not active:                              # (no collective inside this loop: skipping is safe)
                 continue
             b, gt = self.get_batch(data, ids[lo:hi], first_id)
             r = eng.eval_step(b, gt) if self.baseline is None else self.baseline_step(b, gt)
@@ -265,18 +265,26 @@ class Runner:
 
     # ---- checkpoints (counterexamples.py:550-580) -------------------------------------------------------------
     def save(self, save_dir, info, is_best):
-        if self.rank != 0:
-            return
+        """Rank 0 writes; every rank waits for the files (a following --test / --resume load on another rank must not
+        race the write)."""
+        if self.rank == 0:
+            self._save(save_dir, info, is_best)
+        if torch.distributed.is_initialized():
+            torch.distributed.barrier()
+
+    def _save(self, save_dir, info, is_best):
         os.makedirs(os.path.join(save_dir, "ckpt"), exist_ok=True); os.makedirs(os.path.join(save_dir, "best"), exist_ok=True)
         pm, pi = os.path.join(save_dir, "ckpt", "model.ckpt"), os.path.join(save_dir, "ckpt", "info.ckpt")
         state = {k: v.cpu() for k, v in self.engine.state_dict().items()}
         if self.vqa is not None:                  # the reference's state_dict embeds the VQA model (cx.py:56)
             state.update({"vqa_model." + k: v.cpu() for k, v in self.vqa.state_dict().items()})
+        po = os.path.join(save_dir, "ckpt", "optim.ckpt")          # net-new: Adam moments + step (the reference restarts Adam on --resume)
         torch.save(state, pm)
         torch.save(info, pi)
+        torch.save(self.engine.optimizer_state(), po)
         if is_best:
-            shutil.copyfile(pm, os.path.join(save_dir, "best", "model.ckpt"))
-            shutil.copyfile(pi, os.path.join(save_dir, "best", "info.ckpt"))
+            for src in (pm, pi, po):
+                shutil.copyfile(src, os.path.join(save_dir, "best", os.path.basename(src)))
         self.log("{}Saved checkpoint to {}".format("* " if is_best else "", save_dir))
 
     def load(self, save_dir, best):
@@ -285,6 +293,9 @@ class Runner:
         self.engine.load_state({k: v for k, v in state.items() if not k.startswith("vqa_model.")})
         info = torch.load(os.path.join(save_dir, sub, "info.ckpt"))
         assert len(info) > 0
+        po = os.path.join(save_dir, sub, "optim.ckpt")
+        if os.path.isfile(po):                      # (absent in checkpoints written by the reference: Adam restarts, as there)
+            self.engine.load_optimizer_state(torch.load(po, map_location="cpu"))
         last = info[-1]
         return info, len(info) + 1, last.get("recall_5", last.get("recall"))     # the reference KeyErrors here (:580)
 

@@ -44,16 +44,24 @@ def epoch_batches(n_examples: int, global_batch: int, epoch: int, seed: int = 42
 def epoch_plan(n_examples: int, global_batch: int, epoch: int, rank: int, world: int, device, seed: int = 42,
                shuffle: bool = True):
     """The same batches as `epoch_batches` + `shard`, with ONE host-to-device copy per epoch: returns
-    (ids int64 [n_examples] on `device`, [(lo, hi, global_size, first_id)] per global batch) where ids[lo:hi] is this
-    rank's slice.  Per-step index tensors are then device slices: a pageable host-to-device copy per step would
-    make the host wait for the stream to drain every step."""
+    (ids int64 [n_examples] on `device`, [(lo, hi, global_size, first_id, active)] per global batch) where ids[lo:hi] is
+    this rank's slice.  Per-step index tensors are then device slices: a pageable host-to-device copy per step would
+    make the host wait for the stream to drain every step.
+
+    A rank whose slice of a (short, last) global batch is empty -- batchify keeps the partial batch,
+    counterexamples.py:513-515, so len(batch) < world happens -- still gets an entry: ONE padding triplet (the batch's
+    first) with active = False.  It runs the whole step with loss weight 0 (zero gradients), so every rank enters every
+    collective of every step and advances its step counter (Adam bias correction, dropout seeds) in lockstep."""
     batches = epoch_batches(n_examples, global_batch, epoch, seed, shuffle)
     flat = torch.tensor([i for b in batches for i in b], dtype=torch.int64).to(device)
     plan, off = [], 0
     for b in batches:
         n = len(b)
         lo, hi = n * rank // world, n * (rank + 1) // world
-        plan.append((off + lo, off + hi, n, b[lo] if hi > lo else -1))
+        if hi > lo:
+            plan.append((off + lo, off + hi, n, b[lo], True))
+        else:
+            plan.append((off, off + 1, n, b[0], False))          # padding triplet, weight 0
         off += n
     return flat, plan
 

@@ -101,6 +101,18 @@ class NeuralCXEngine:
     def state_dict(self):
         return {n: v.detach().clone() for n, v in self.params.views.items()}
 
+    def optimizer_state(self):
+        """Adam moments + step counter (net-new: the reference checkpoints the model only, counterexamples.py:550-560, so
+        its --resume restarts Adam; with this a resumed run continues bit for bit)."""
+        return {"exp_avg": self.exp_avg.detach().cpu(), "exp_avg_sq": self.exp_avg_sq.detach().cpu(), "step": self.step_count,
+                "numel": self.params.numel}
+
+    def load_optimizer_state(self, st):
+        if st["numel"] != self.params.numel:
+            raise ValueError("optimizer state of another model (%d vs %d parameters)" % (st["numel"], self.params.numel))
+        self.exp_avg.copy_(st["exp_avg"].to(self.device)); self.exp_avg_sq.copy_(st["exp_avg_sq"].to(self.device))
+        self.step_count = int(st["step"])
+
     # ---- steps -------------------------------------------------------------------------------------------
     def _dims(self, batch: ops.Batch, training: bool, loss_scale: float):
         c = self.cfg
@@ -129,8 +141,10 @@ class NeuralCXEngine:
         r["scores"] = scores
         return r
 
-    def train_step(self, batch: ops.Batch, gt: torch.Tensor, global_batch: Optional[int] = None):
-        """forward + loss + backward + (all-reduce) + Adam.  Returns device tensors; never syncs the host."""
+    def train_step(self, batch: ops.Batch, gt: torch.Tensor, global_batch: Optional[int] = None, active: bool = True):
+        """forward + loss + backward + (all-reduce) + Adam.  Returns device tensors; never syncs the host.
+        active = False (data parallelism, dp.epoch_plan): `batch` is a padding triplet -- the step runs with loss weight 0,
+        i.e. this rank adds exact zeros to every gradient sum but enters every collective and steps its optimizer."""
         B = batch.img_idx.shape[0]
         gb = global_batch if global_batch is not None else B * self.world_size
         self.step_count += 1
@@ -138,6 +152,9 @@ class NeuralCXEngine:
         d = self._dims(batch, True, 1.0 / gb)
         scores = ops.forward(d, batch, self.params.fields(), self._ws)
         r = ops.ranking_loss(scores, gt, scale=1.0 / gb)
+        if not active:
+            for k in ("dscores", "loss", "loss_rows", "hits"):
+                r[k].zero_()
         if self.world_size > 1:
             # The embedding gradient dE = dGt^T.W1ak + dGgt^T.W1agt is linear in the 2 x [H, A] block dGt | dGgt: the
             # ranks sum THAT block (4 MB at H=256) and each computes the complete dE itself, so the 19 MB [A, da]
@@ -172,7 +189,5 @@ class NeuralCXEngine:
     # ---- configs[2]: MUTAN multimodal features produced on the fly ---------------------------------
     def make_batch_from_vqa(self, feats, img_idx, q_emb, answer_aids, mutan_weights):
         """Inputs of NeuralCX from the frozen MUTAN producer (ncx_vqa_forward) instead of precomputed z / a blocks."""
-        if getattr(self, "_vqa_ws", None) is None:
-            self._vqa_ws = None
         _, z_o, a_k, z_k = ops.vqa_forward(feats, img_idx, q_emb, mutan_weights, want_a_orig=False)
         return ops.Batch(feats, img_idx, q_emb, z_o, z_k, a_k, answer_aids)

@@ -91,9 +91,12 @@ def load_answer_embedding(path: str, n_answers: Optional[int] = None, dim_a: int
     return emb
 
 
-def examples_to_index_arrays(examples: Sequence[dict], name_to_index: Dict[str, int], knn_size: int = 24):
+def examples_to_index_arrays(examples: Sequence[dict], name_to_index: Dict[str, int], knn_size: int = 24,
+                             n_answers: Optional[int] = None):
     """Whole example list -> (img_idx int32 [N, K+1], question_wids int64 [N, T], answer_aids int32 [N],
-    comp_idxs int32 [N]): the per-batch lookups of getDataFromBatch (counterexamples.py:525-537) done once."""
+    comp_idxs int32 [N]): the per-batch lookups of getDataFromBatch (counterexamples.py:525-537) done once.
+    n_answers: when given, answer_aid is range-checked here (the kernels gather / scatter answer_embedding rows by it;
+    the reference's nn.Embedding raises an index error for a bad id, cx.py:280)."""
     n = len(examples)
     img_idx = np.empty((n, knn_size + 1), np.int32)
     aids = np.empty(n, np.int32)
@@ -114,6 +117,8 @@ def examples_to_index_arrays(examples: Sequence[dict], name_to_index: Dict[str, 
         comps[i] = ex["comp"]["knn_index"]
     if n and (comps.min() < 0 or comps.max() >= knn_size):
         raise ValueError("comp.knn_index outside [0, %d)" % knn_size)
+    if n and n_answers is not None and (aids.min() < 0 or aids.max() >= n_answers):
+        raise IndexError("answer_aid outside [0, %d) (example %d)" % (n_answers, int(np.argmax((aids < 0) | (aids >= n_answers)))))
     return img_idx, wids, aids, comps
 
 
@@ -125,7 +130,8 @@ class CXDeviceDataset:
         self.device = torch.device(device)
         self.K = knn_size
         self.vocab_words, self.vocab_answers = data["vocab_words"], data["vocab_answers"]
-        img_idx, wids, aids, comps = examples_to_index_arrays(data["examples_list"], data["name_to_index"], knn_size)
+        img_idx, wids, aids, comps = examples_to_index_arrays(data["examples_list"], data["name_to_index"], knn_size,
+                                                              n_answers=len(self.vocab_answers) or None)
         self.N = img_idx.shape[0]
         n_rows = features.shape[0] if feats is None else feats.shape[0]
         if self.N and (img_idx.min() < 0 or img_idx.max() >= n_rows):

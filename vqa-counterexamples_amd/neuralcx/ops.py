@@ -251,30 +251,56 @@ def vqa_forward(feats: torch.Tensor, img_idx: torch.Tensor, q_emb: torch.Tensor,
     return a_o, z_o, a_k, z_k
 
 
+class WorkspacePool:
+    """Workspaces (saved activations + scratch of ncx_forward / ncx_backward) of one module.  A workspace is OWNED by the
+    call that took it until that call's backward has been enqueued (or, for a call that needs no gradient, until its
+    forward has been enqueued -- the stream orders the reuse); only then does it return to the pool.  Two forwards
+    before a backward therefore never share saved activations (the reference module has no such limit either:
+    counterexamples.py:357-361 evaluates inside the train loop)."""
+
+    def __init__(self):
+        self.free = []
+
+    def take(self, nbytes: int, device) -> torch.Tensor:
+        for i, w in enumerate(self.free):
+            if w.numel() >= nbytes and w.device == device:
+                return self.free.pop(i)
+        self.free.clear()                       # (sizes changed: drop the stale buffers)
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def give(self, ws: torch.Tensor) -> None:
+        if len(self.free) < 2:
+            self.free.append(ws)
+
+
 class NeuralCXFunction(torch.autograd.Function):
-    """scores = NeuralCX(batch; params) with the hand-written backward (ncx_backward)."""
+    """scores = NeuralCX(batch; params) with the hand-written backward (ncx_backward).
+    `call` = {dims, batch, names, pool, record}: a per-call snapshot -- backward reads the dims / inputs / workspace of ITS
+    forward from ctx, never from shared module state."""
 
     @staticmethod
-    def forward(ctx, holder, *param_tensors):
-        d, batch, names = holder["dims"], holder["batch"], holder["names"]
+    def forward(ctx, call, *param_tensors):
+        d, batch, names, pool = call["dims"], call["batch"], call["names"], call["pool"]
         params = dict(zip(names, param_tensors))
-        ws = holder.get("workspace")
-        need = workspace_bytes(d) + 256
-        if ws is None or ws.numel() < need or ws.device != batch.feats.device:
-            ws = torch.empty(need, dtype=torch.uint8, device=batch.feats.device)
-            holder["workspace"] = ws
+        ws = pool.take(workspace_bytes(d) + 256, batch.feats.device)
         scores = forward(d, batch, params, ws)
-        ctx.holder, ctx.ws = holder, ws
-        ctx.save_for_backward(*param_tensors)
+        if call["record"]:                      # (ctx.needs_input_grad stays True under torch.no_grad: the caller tells)
+            ctx.call, ctx.ws = dict(call), ws
+            ctx.save_for_backward(*param_tensors)
+        else:
+            pool.give(ws)                       # no graph is recorded (torch.no_grad / frozen parameters)
         return scores
 
     @staticmethod
     def backward(ctx, dscores):
-        holder = ctx.holder
-        d, batch, names = holder["dims"], holder["batch"], holder["names"]
+        call = ctx.call
+        if ctx.ws is None:
+            raise RuntimeError("NeuralCXFunction: backward ran twice on one forward (retain_graph is not supported: "
+                               "the saved activations live in a workspace that has been released)")
+        d, batch, names = call["dims"], call["batch"], call["names"]
         params = dict(zip(names, ctx.saved_tensors))
-        gbuf = holder.get("grad_buffers")
-        if gbuf is None:
-            gbuf = {n: torch.empty_like(t) for n, t in params.items()}
+        gbuf = {n: torch.empty_like(t) for n, t in params.items()}
         backward(d, batch, params, ctx.ws, dscores.contiguous(), gbuf)
+        call["pool"].give(ctx.ws)
+        ctx.ws = None
         return (None,) + tuple(gbuf[n] for n in names)

@@ -121,8 +121,8 @@ class NeuralModel(CXModelBase):
                          trainable_vqa=kwargs.get("trainable_vqa", False))
         if self.trainable_vqa:
             raise NotImplementedError("trainable_vqa=True is not supported by the HIP path (frozen VQA model only)")
-        if not 1 <= self.knn_size <= 64:
-            raise ValueError("knn_size must be in 1..64")
+        if not 3 <= self.knn_size <= 64:         # (the reference asserts knn_size == 24, cx.py:226; the kernels' 16-byte
+            raise ValueError("knn_size must be in 3..64")     #  row windows need K + 1 >= 4 columns in the dist | rank block)
         if n_layers not in (1, 2, 3):
             raise ValueError("n_layers must be 1, 2 or 3")
         self.model_spec = dict(model_spec)
@@ -146,7 +146,7 @@ class NeuralModel(CXModelBase):
         self.out = nn.Linear(dim_h, 1)
         self.relu = nn.ReLU()
         self.drop = nn.Dropout(p=drop_p)
-        self._holder = {}
+        self._pool = ops.WorkspacePool()
         self._step = 0
         self.dropout_seed = 42
 
@@ -175,8 +175,9 @@ class NeuralModel(CXModelBase):
         d = ops.make_dims(batch, H=self.dim_h, L=self.n_layers, da=self.dim_a, A=self.ans_size,
                           flags=ops.flags_from_spec(self.model_spec), training=self.training,
                           drop_p=self.drop_p if self.training else 0.0, seed=(self.dropout_seed << 32) ^ self._step)
-        self._holder.update(dims=d, batch=batch, names=names)
-        return ops.NeuralCXFunction.apply(self._holder, *tensors)
+        record = torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
+        call = dict(dims=d, batch=batch, names=names, pool=self._pool, record=record)      # per-call snapshot (re-entrant: see ops.WorkspacePool)
+        return ops.NeuralCXFunction.apply(call, *tensors)
 
     def forward(self, image_features, question_wids, answer_aids):
         spec = self.model_spec
@@ -200,6 +201,12 @@ class NeuralModel(CXModelBase):
             extra["a_emb_gt"] = torch.rand(B, self.dim_a, device=dev)
         if not spec.get("v_rank", True):                                        # cx.py:306-307
             extra["v_rank"] = torch.rand(B, K, K, device=dev)
+        if spec.get("a_emb", True) and answer_aids.numel():
+            # nn.Embedding raises on a bad index (cx.py:280); the kernels gather / scatter embedding rows by it, so check
+            # here (one host sync; the reference's loop syncs every step anyway: recallAtK, counterexamples.py:333)
+            lo, hi = int(answer_aids.min()), int(answer_aids.max())
+            if lo < 0 or hi >= self.ans_size:
+                raise IndexError("answer_aids outside [0, %d): [%d, %d]" % (self.ans_size, lo, hi))
         batch = ops.Batch.from_dense(image_features.float(), q_emb.float(), z_orig.float(), z_knns.float(),
                                      a_knns.float(), answer_aids, **extra)
         return self.score_batch(batch)
