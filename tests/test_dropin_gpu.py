@@ -545,7 +545,7 @@ def _dp_idle_rank_worker(rank, world, port, q):
     eng = NeuralCXEngine(K=d.K, dv=d.dv, dq=d.dq, dz=d.dz, da=d.da, A=d.A, H=d.H, L=d.L, drop_p=0.0, lr=1e-3, device=DEV, world_size=world)
     eng.rank = rank
     eng.load_state(orc.init_params(d, seed=4, gain=2.0))
-    ids, plan = dp.epoch_plan(5, 4, 1, rank, world, "cpu", shuffle=False)      # batches of 4 and 1: rank 1 idles in the second
+    ids, plan = dp.epoch_plan(5, 4, 1, rank, world, "cpu", shuffle=False)      # batches of 4 and 1: rank 0 idles in the second
     for lo, hi, n_global, first, active in plan:
         sel = ids[lo:hi]
         sub = {k: v[sel] for k, v in batch.items()}
@@ -574,7 +574,7 @@ def test_dp2_rank_without_triplets_still_steps_in_lockstep():
     assert all(p.exitcode == 0 for p in procs)
     outs.sort(key=lambda o: o["__rank__"])
     assert outs[0]["__step__"] == outs[1]["__step__"] == 2
-    assert outs[1]["__loss__"] == 0.0                            # the idle rank reports no loss
+    assert outs[0]["__loss__"] == 0.0 and outs[1]["__loss__"] > 0.0     # rank 0's slice of the 1-triplet batch is empty: it reports no loss
     d = orc.Dims(dv=96, dq=64, dz=24, A=40, H=64, L=1)
     batch = _dp_batch(d, 5)
     eng = NeuralCXEngine(K=d.K, dv=d.dv, dq=d.dq, dz=d.dz, da=d.da, A=d.A, H=d.H, L=d.L, drop_p=0.0, lr=1e-3, device=DEV)
@@ -585,5 +585,10 @@ def test_dp2_rank_without_triplets_still_steps_in_lockstep():
     ref = {k: v.cpu().numpy() for k, v in eng.state_dict().items()}
     for k, v in ref.items():
         assert np.array_equal(outs[0][k], outs[1][k]), k           # replicas identical
-        if k != "out.bias":                                        # (zero gradient in maths: Adam amplifies its round-off)
-            assert np.abs(outs[0][k] - v).max() <= 2e-5 * max(np.abs(v).max(), 1e-3), k
+        # against the single-process run: Adam normalises by sqrt(v), so entries whose gradient is round-off noise (the
+        # columns of linear_1 that meet all-zero inputs, out.bias) move by up to +-lr per step either way; everything
+        # else agrees to summation order
+        diff = np.abs(outs[0][k] - v)
+        assert diff.max() <= 2 * 1e-3 + 1e-6, k                    # never more than two steps of lr apart
+        if k != "out.bias":
+            assert (diff > 2e-6).mean() <= 0.02, (k, float((diff > 2e-6).mean()))

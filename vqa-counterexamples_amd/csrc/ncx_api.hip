@@ -91,11 +91,11 @@ __global__ __launch_bounds__(256) void k_prep(ncx_dims d, ncx_inputs in, int* __
         }
         dist = sqrtf(wave_sum(s));
     }
-    const int mw = d.K + 1;
+    const int mw = pad_to(d.K + 1, 4);                        // (zero padded to whole 16-byte windows: ncx_main.h)
     float* mrow = misc + (long long)r * mw;
     if (lane == 0) mrow[0] = dist;
-    for (int j = lane; j < d.K; j += 64)
-        mrow[1 + j] = (d.flags & NCX_F_V_RANK) ? (j == k ? 1.f : 0.f) : in.v_rank[((long long)r) * d.K + j];
+    for (int j = lane; j < mw - 1; j += 64)
+        mrow[1 + j] = j >= d.K ? 0.f : (d.flags & NCX_F_V_RANK) ? (j == k ? 1.f : 0.f) : in.v_rank[((long long)r) * d.K + j];
     if (xc) {               // NCX_F_BF16: [ v_k | v_o * v_k | dist, rank | z_k | softmax (below) ], zero in the gaps
         if (RESIDENT) {
 #pragma unroll
@@ -481,6 +481,38 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     }
 }
 
+// Padded weight copies (ncx_main.h reads every weight row up to the next multiple of 32 columns).  Slot i of the wpad region:
+//   0 v_other  1 v_mult  2 dist | rank  3 z_other  4 a_other (a_emb lesion only)  5 linear_2  6 linear_3
+// width 0: the slice is used in place (already a multiple of 32 wide, or the segment does not exist).
+constexpr int WPAD_N = 7;
+static inline int wpad_cols(const ncx_dims& d, int i) {
+    switch (i) {
+    case 0: return d.dv;
+    case 1: return (d.flags & NCX_F_V_MULT) ? d.dv : 0;
+    case 2: return d.K + 1;
+    case 3: return d.dz;
+    case 4: return (d.flags & NCX_F_A_EMB) ? 0 : d.da;
+    case 5: return d.L >= 2 ? d.H : 0;
+    default: return d.L >= 3 ? d.H : 0;
+    }
+}
+static inline int wpad_width(const ncx_dims& d, int i) {
+    const int c = wpad_cols(d, i);
+    if (d.flags & NCX_F_BF16) return 0;
+    return (c == 0 || c % 32 == 0) ? 0 : pad_to(c, 32);
+}
+struct PackArgs { const float* src[WPAD_N + 1]; float* dst[WPAD_N + 1]; long long lds[WPAD_N + 1]; int cols[WPAD_N + 1], ldd[WPAD_N + 1], zero_from[WPAD_N + 1]; int n, H; };
+// dst[e][h][0 .. cols) = src[e][h][0 .. cols);  dst[e][h][zero_from .. ldd) = 0.   grid (H, n)
+__global__ __launch_bounds__(256) void k_pack_rows(const PackArgs a) {
+    const int h = blockIdx.x, e = blockIdx.y;
+    float* drow = a.dst[e] + (long long)h * a.ldd[e];
+    if (a.src[e]) {
+        const float* srow = a.src[e] + (long long)h * a.lds[e];
+        for (int c = threadIdx.x; c < a.cols[e]; c += 256) drow[c] = srow[c];
+    }
+    for (int c = a.zero_from[e] + threadIdx.x; c < a.ldd[e]; c += 256) drow[c] = 0.f;
+}
+
 // =================================================================================================
 // planning
 // =================================================================================================
@@ -672,8 +704,10 @@ WsLayout ws_layout(const ncx_dims& d) {
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     w.idx_k = take(M * 4); w.idx_o = take(M * 4); w.idx_ob = take((size_t)d.B * 4);
     w.mx = take(M * 4); w.inv = take(M * 4);
-    w.misc = take(M * (d.K + 1) * 4);
-    w.gt = take(H * d.A * 4);
+    w.ldm = pad_to(d.K + 1, 4);
+    w.ldgt = (d.flags & NCX_F_BF16) ? d.A : pad_to(d.A, 32);
+    w.misc = take(M * w.ldm * 4);
+    w.gt = take(H * w.ldgt * 4);
     w.sh = take((size_t)d.B * H * 4);
     for (int l = 0; l < 3; ++l) w.h[l] = l < d.L ? take(M * H * 4) : 0;
     w.dpre[0] = take(M * H * 4);
@@ -696,6 +730,11 @@ WsLayout ws_layout(const ncx_dims& d) {
         w.slab2 = take(w.slab2_bytes);
     }
     w.km_slab = take(dw_km_slab_bytes(d));
+    {   // padded weight copies for the fused forward kernel: [H][pad32(width)] each, in the order pack_wpad fills them
+        size_t e = 0;
+        for (int i = 0; i < WPAD_N; ++i) e += (size_t)H * wpad_width(d, i);
+        w.wpad = take(e * 4);
+    }
     if (d.flags & NCX_F_BF16) {                          // packed bf16 operands of the two dominant GEMMs (ncx_bf16.h)
         w.xc = take(bf16_xc_bytes(d)); w.wc = take(bf16_wc_bytes(d));
         w.dpre_bf = take(bf16_dpre_bytes(d)); w.bf_slab = take(bf16_slab_bytes(d));
@@ -876,6 +915,26 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
                            bf16_cols(d));
     NCX_HIP_TRY(hipGetLastError());
 
+    // zero-padded copies of the weight slices the fused forward kernel reads past their width (+ the pad columns of Gt):
+    // functions of the weights only, like Gt -- evaluation passes reuse them (NCX_F_REUSE_GT)
+    struct { const float* ptr[WPAD_N]; int width[WPAD_N]; } wp{};
+    {
+        const float* srcs[WPAD_N] = {p->w1 + o.v_other, p->w1 + o.v_mult, p->w1 + o.v_dist, p->w1 + o.z_other, p->w1 + o.a_other, p->w2, p->w3};
+        PackArgs pk{}; pk.H = H;
+        float* cur = (float*)(ws + w.wpad);
+        for (int i = 0; i < WPAD_N; ++i) {
+            wp.width[i] = wpad_width(d, i); wp.ptr[i] = cur;
+            if (!wp.width[i]) continue;
+            const int e = pk.n++;
+            pk.src[e] = srcs[i]; pk.lds[e] = i >= 5 ? H : din; pk.cols[e] = wpad_cols(d, i); pk.dst[e] = cur; pk.ldd[e] = wp.width[i]; pk.zero_from[e] = pk.cols[e];
+            cur += (size_t)H * wp.width[i];
+        }
+        if (aemb && w.ldgt > d.A) { const int e = pk.n++; pk.src[e] = nullptr; pk.dst[e] = gt; pk.ldd[e] = w.ldgt; pk.zero_from[e] = d.A; pk.cols[e] = 0; }
+        if (pk.n && !(d.flags & NCX_F_REUSE_GT)) {
+            hipLaunchKernelGGL(k_pack_rows, dim3(H, pk.n), dim3(256), 0, s, pk);
+            NCX_HIP_TRY(hipGetLastError());
+        }
+    }
     // Gt[H, A] = W1[:, a_other] . E^T   (weights only: evaluation passes reuse it, NCX_F_REUSE_GT)
     if (aemb && bf16 && !(d.flags & NCX_F_REUSE_GT)) {       // bf16 copies of E / W1[:, a_*] (also the backward's operands)
         const Bf16Emb m = bf16_emb_layout(d, ws + w.bf_emb);
@@ -887,7 +946,7 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
         GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = H;
         a.a[0] = x_plain(p->w1 + o.a_other, din, H, d.da);
         a.b[0] = x_plain(p->answer_embedding, d.da, d.A, d.da);
-        a.klen[0] = d.da; a.out[0] = gt; a.ldo[0] = d.A; a.n_cols[0] = d.A;
+        a.klen[0] = d.da; a.out[0] = gt; a.ldo[0] = w.ldgt; a.n_cols[0] = d.A;
         rc = run_gemm(U_GT, a, FORM_NT, u[U_GT].plan, slab_side, slab_side_bytes, nullptr, s2);
         if (rc) return rc;
     }
@@ -916,16 +975,35 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
         rc = prof_open(U_MAIN, s); if (rc) return rc;
         rc = bf16_main_forward(d, xc, (const u16*)(ws + w.wc), e, (float*)(ws + w.h[0]), s); if (rc) return rc;
         rc = prof_close(U_MAIN, s); if (rc) return rc;
-    } else {
+    } else if (main_fwd_dims_ok(d)) {        // the fused forward kernel (ncx_main.h): weights zero-padded to 32 columns
+        MainArgs a{}; a.M = M; a.N = H;
+        int n = 0;
+        auto seg = [&](int kind, const float* x, long long lda, int klen, const int* i1, const int* i2, const float* lse, int slot, const float* wgt, long long ldb) {
+            MainSeg& g = a.seg[n++]; g.kind = kind; g.a = x; g.lda = lda; g.idx = i1; g.idx2 = i2; g.lse = lse; g.klen = klen;
+            if (slot >= 0 && wp.width[slot]) { g.b = wp.ptr[slot]; g.ldb = wp.width[slot]; } else { g.b = wgt; g.ldb = ldb; } };
+        seg(MK_GATHER, in->feats, d.dv, d.dv, idx_k, nullptr, nullptr, 0, p->w1 + o.v_other, din);
+        if (d.flags & NCX_F_V_MULT) seg(MK_GATHER_MUL, in->feats, d.dv, d.dv, idx_k, idx_o, nullptr, 1, p->w1 + o.v_mult, din);
+        seg(MK_PLAIN, misc, w.ldm, w.ldm, nullptr, nullptr, nullptr, 2, p->w1 + o.v_dist, din);       // (ldm - K - 1 zero columns on both sides)
+        seg(MK_PLAIN, in->z_knns, d.dz, d.dz, nullptr, nullptr, nullptr, 3, p->w1 + o.z_other, din);
+        if (aemb) seg(MK_SOFTMAX, in->a_knns, d.A, d.A, nullptr, nullptr, mx, -1, gt, w.ldgt);
+        else      seg(MK_PLAIN, in->a_knns, d.da, d.da, nullptr, nullptr, nullptr, 4, p->w1 + o.a_other, din);
+        a.nseg = n;
+        a.out = (float*)(ws + w.h[0]); a.ldo = H;
+        a.epi.rowadd = sh; a.epi.ld_rowadd = H; a.epi.rowdiv = d.K;
+        set_dropout(a.epi, d, *in, 1, M);
+        rc = prof_open(U_MAIN, s); if (rc) return rc;
+        rc = main_forward(a, s); if (rc) return rc;
+        rc = prof_close(U_MAIN, s); if (rc) return rc;
+    } else {                                  // widths that are not multiples of 4: the generic segmented engine
         GemmArgs a{}; a.mode = MODE_CHAIN; a.M = M;
         int n = 0;
         a.a[n] = x_gather(in->feats, d.dv, idx_k, M, d.dv); a.b[n] = x_plain(p->w1 + o.v_other, din, H, d.dv); a.klen[n] = d.dv; ++n;
         if (d.flags & NCX_F_V_MULT) {
             a.a[n] = x_gather_mul(in->feats, d.dv, idx_k, idx_o, M, d.dv); a.b[n] = x_plain(p->w1 + o.v_mult, din, H, d.dv); a.klen[n] = d.dv; ++n;
         }
-        a.a[n] = x_plain(misc, d.K + 1, M, d.K + 1); a.b[n] = x_plain(p->w1 + o.v_dist, din, H, d.K + 1); a.klen[n] = d.K + 1; ++n;
+        a.a[n] = x_plain(misc, w.ldm, M, d.K + 1); a.b[n] = x_plain(p->w1 + o.v_dist, din, H, d.K + 1); a.klen[n] = d.K + 1; ++n;
         a.a[n] = x_plain(in->z_knns, d.dz, M, d.dz); a.b[n] = x_plain(p->w1 + o.z_other, din, H, d.dz); a.klen[n] = d.dz; ++n;
-        if (aemb) { a.a[n] = x_softmax(in->a_knns, d.A, mx, inv, M, d.A); a.b[n] = x_plain(gt, d.A, H, d.A); a.klen[n] = d.A; ++n; }
+        if (aemb) { a.a[n] = x_softmax(in->a_knns, d.A, mx, inv, M, d.A); a.b[n] = x_plain(gt, w.ldgt, H, d.A); a.klen[n] = d.A; ++n; }
         else      { a.a[n] = x_plain(in->a_knns, d.da, M, d.da); a.b[n] = x_plain(p->w1 + o.a_other, din, H, d.da); a.klen[n] = d.da; ++n; }
         a.nseg = n;
         a.out[0] = (float*)(ws + w.h[0]); a.ldo[0] = H; a.n_cols[0] = H;
@@ -937,13 +1015,26 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
     for (int l = 2; l <= d.L; ++l) {
         const float* wl = l == 2 ? p->w2 : p->w3;
         const float* bl = l == 2 ? p->b2 : p->b3;
-        GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = M;
-        a.a[0] = x_plain((const float*)(ws + w.h[l - 2]), H, M, H); a.b[0] = x_plain(wl, H, H, H); a.klen[0] = H;
-        a.out[0] = (float*)(ws + w.h[l - 1]); a.ldo[0] = H; a.n_cols[0] = H;
-        a.epi.bias = bl;
-        set_dropout(a.epi, d, *in, l, M);
-        rc = run_gemm(U_FWD_L, a, FORM_NT, u[U_FWD_L].plan, slab, w.slab_bytes, nullptr, s);
-        if (rc) return rc;
+        if (hidden_fwd_dims_ok(d) && !bf16) {
+            MainArgs a{}; a.M = M; a.N = H; a.nseg = 1;
+            MainSeg& g = a.seg[0]; g.kind = MK_PLAIN; g.a = (const float*)(ws + w.h[l - 2]); g.lda = H; g.klen = H;
+            const int slot = 3 + l;                                       // 5: linear_2, 6: linear_3
+            if (wp.width[slot]) { g.b = wp.ptr[slot]; g.ldb = wp.width[slot]; } else { g.b = wl; g.ldb = H; }
+            a.out = (float*)(ws + w.h[l - 1]); a.ldo = H;
+            a.epi.bias = bl;
+            set_dropout(a.epi, d, *in, l, M);
+            rc = prof_open(U_FWD_L, s); if (rc) return rc;
+            rc = main_forward(a, s); if (rc) return rc;
+            rc = prof_close(U_FWD_L, s); if (rc) return rc;
+        } else {
+            GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = M;
+            a.a[0] = x_plain((const float*)(ws + w.h[l - 2]), H, M, H); a.b[0] = x_plain(wl, H, H, H); a.klen[0] = H;
+            a.out[0] = (float*)(ws + w.h[l - 1]); a.ldo[0] = H; a.n_cols[0] = H;
+            a.epi.bias = bl;
+            set_dropout(a.epi, d, *in, l, M);
+            rc = run_gemm(U_FWD_L, a, FORM_NT, u[U_FWD_L].plan, slab, w.slab_bytes, nullptr, s);
+            if (rc) return rc;
+        }
     }
     hipLaunchKernelGGL(k_scores, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, s, (const float*)(ws + w.h[d.L - 1]),
                        p->w_out, p->b_out, scores, M, H);
@@ -1111,7 +1202,7 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
         if (want_dgt) add_c(x_softmax(in->a_knns, d.A, mx, inv, M, d.A), dgt, d.A);
         if (want_rest && !bf16) {      // the narrow problems last among the candidate ones (shorter k-chunks: see dw1c_seg_split)
             add_c(x_plain(in->z_knns, d.dz, M, d.dz), g->w1 + o.z_other, din);
-            add_c(x_plain(misc, d.K + 1, M, d.K + 1), g->w1 + o.v_dist, din);
+            add_c(x_plain(misc, w.ldm, M, d.K + 1), g->w1 + o.v_dist, din);
         }
         if (want_rest) {
             add_s(x_gather(in->feats, d.dv, idx_ob, d.B, d.dv), g->w1 + o.v_orig);

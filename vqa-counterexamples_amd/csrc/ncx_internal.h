@@ -60,9 +60,31 @@ struct WsLayout {
     size_t xc, wc, dpre_bf, bf_slab;    // NCX_F_BF16: packed bf16 candidate rows / weights / dpre, k-chunk slabs of dWc
     size_t bf_emb;                      // NCX_F_BF16: bf16 images of E, E^T, [W1ak; W1agt], [dGt; dGgt]
     size_t km_slab;                     // k-chunk slabs of the fused v_other / v_mult weight gradient (ncx_dwkm.hip)
+    size_t wpad;                        // zero-padded copies of the weight slices whose width is not a multiple of 32 (ncx_main.h)
+    int ldm;                            // leading dimension of misc: K + 1 rounded up to a multiple of 4 (zero padded)
+    int ldgt;                           // leading dimension of Gt: A rounded up to a multiple of 32 (zero padded); bf16 variant: A
     size_t total;
 };
 constexpr int NCX_COLSUM_CHUNKS = 256;
+
+// ncx_main.hip: the fused forward kernel of the Linear layers (segments of never-materialised operands chained into one
+// accumulator; Sh / bias / ReLU / Dropout in the epilogue)
+enum MainKind : int { MK_PLAIN = 0, MK_GATHER = 1, MK_GATHER_MUL = 2, MK_SOFTMAX = 3 };
+constexpr int MAIN_MAX_SEG = 5;
+struct MainSeg {
+    const float* a;      // operand rows: x(r, c) = a[row(r) * lda + c], row(r) = r or idx[r]
+    const int*   idx;    // MK_GATHER / MK_GATHER_MUL: table row of logical row r
+    const int*   idx2;   // MK_GATHER_MUL: x(r, c) = a[idx[r]][c] * a[idx2[r]][c]        (v_other * v_orig, cx.py:296)
+    const float* lse;    // MK_SOFTMAX: x(r, c) = exp2(a[r][c] * log2(e) - lse[r])        (softmax(a_knns), cx.py:281)
+    const float* b;      // weight slice: w(n, c) = b[n * ldb + c]
+    long long lda, ldb;
+    int kind, klen;      // klen: reduction extent (columns of the segment), >= 4
+};
+struct MainArgs {
+    MainSeg seg[MAIN_MAX_SEG]; int nseg, M, N, pad_; float* out; long long ldo; EpiArgs epi;
+    unsigned long long* stamps;      // diagnostics (tools/mb/mb_main.hip): 16 words per workgroup of s_memtime / s_memrealtime stamps; NULL in the library
+};
+int main_forward(MainArgs& a, hipStream_t s);
 
 // ncx_dwkm.hip: d linear_1.weight[:, v_other] and [:, v_mult] in one MFMA pass with a per-triplet fold
 constexpr int DW_KM_SPLIT = 8;
@@ -71,5 +93,12 @@ size_t dw_km_slab_bytes(const ncx_dims& d);
 int dw_km(const ncx_dims& d, const float* dpre, const float* feats, const int* idx_k, const int* idx_o, float* slab,
           float* g_vother, float* g_vmult, long long din, hipStream_t s);
 WsLayout ws_layout(const ncx_dims& d);
+__host__ __device__ static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
+// The fused forward kernel (ncx_main.h) takes operands whose widths are multiples of 4 (16-byte windows, no straddling);
+// other shapes (only the ragged test shapes: every real width is a multiple of 8) run on the generic engine.
+static inline bool main_fwd_dims_ok(const ncx_dims& d) {
+    return d.dv % 4 == 0 && d.dz % 4 == 0 && ((d.flags & NCX_F_A_EMB) ? d.A : d.da) % 4 == 0 && !(d.flags & NCX_F_BF16);
+}
+static inline bool hidden_fwd_dims_ok(const ncx_dims& d) { return d.H % 4 == 0; }
 
 }  // namespace ncx

@@ -1,0 +1,350 @@
+// ncx_main.h -- the fused forward kernel of the scoring MLP's Linear layers (gfx950, fp32 MFMA).
+//
+//   h[r, n] = epilogue( sum over segments s of  X_s[r, :] . W_s[n, :]^T  (+ Sh[r / K, n]) (+ bias[n]) )
+//
+// linear_1 of NeuralModel.forward (vqa/models/cx.py:309-322) is the chain of the five per-candidate segments
+// [v_k | v_o*v_k | dist,rank | z_k | softmax(a_k)] against [W1 column slices | Gt]; the torch.cat is never built: every
+// segment is a (never materialised operand, weight slice) pair accumulated into the same MFMA accumulators, the
+// per-triplet shared part Sh[b] enters in the epilogue together with ReLU and Dropout (cx.py:322).  Hidden layers
+// (linear_2/3, cx.py:323-326) are the same kernel with one plain segment and a bias.
+//
+// Structure (measured with tools/mb/mb_gemm.hip and tools/mb/mb_main.hip at the configs[1] shape, 41 GF):  one 96x128
+// workgroup per CU with the whole register file ran 340-355 us; TWO OR MORE independent workgroups per CU (48x128, 96x64 or
+// 64x64 tiles) 310-320 us (130 TFLOP/s): a workgroup parked at its barrier or waiting for its first fragment reads leaves the
+// matrix pipes to the other one.  256 threads = 4 waves, 32-deep k-steps, double-buffered LDS (pitch 36: conflict-free
+// ds_read_b64 fragment reads, two MFMAs per read), global loads issued one or two k-steps before their LDS store, and a
+// ROTATED loop: the MFMAs of a step's last sub-step are issued after the barrier, so they cover the first fragment reads of
+// the next tile.
+//
+// The k-step is ONE basic block, always (in-kernel stamps showed branches inside it costing 15 %: hipcc cannot interleave
+// MFMAs with loads / LDS stores across them).  What makes that possible:
+//   * ragged reduction extents need no code: the WEIGHT side of every segment is zero-padded to a multiple of 32 columns
+//     (ncx_api.hip packs padded copies of the slices that need it; Gt is allocated padded), the OPERAND side only has to
+//     be a multiple of 4 wide: its 16-byte loads are windows slid left to stay inside the row, so a window beyond the
+//     extent re-reads valid (finite) columns that meet zero weights;
+//   * rows beyond the matrix / the tile are clamped loads into spare LDS rows, never predicated;
+//   * a segment's last step (nothing left to store) is its own instantiation; it loads the NEXT segment's first tiles, so a
+//     segment switch costs a barrier, not a round trip to memory.  The sequence of operand kinds is a template parameter
+//     (five sequences exist: linear_1 with / without the v_mult and a_emb lesions, and the hidden layers), so every such
+//     hand-over is compiled for its two kinds and the register allocator sees exactly what is live where.
+#pragma once
+#include "ncx_internal.h"
+#include <type_traits>
+
+namespace ncx {
+
+constexpr int MF_BK = 32, MF_P = MF_BK + 4, MF_T = 256;
+
+// loop kinds: how a tile's registers become LDS values (the row gather only changes the pointer set-up)
+enum { LK_PLAIN = 0, LK_MUL = 1, LK_SOFTMAX = 2 };
+template <int V> struct IntC { static constexpr int value = V; };
+
+// BM x BN tile, 4 waves as WGM x WGN, DEPTH register sets of global loads in flight, OCC workgroups per CU (register budget)
+template <int BM_, int BN_, int WGM_, int WGN_, int DEPTH_, int OCC_>
+struct MainCfg {
+    static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, DEPTH = DEPTH_, OCC = OCC_;
+    static constexpr int BM_LDS = (BM + 31) / 32 * 32;            // A rows held in LDS (a multiple of the 32-row loader pass)
+    static constexpr int LDS = 2 * (BM_LDS + BN) * MF_P * 4;
+};
+
+typedef const __attribute__((address_space(1))) float* gfptr;      // global address space: global_load, never flat_load
+typedef const __attribute__((address_space(1))) int* giptr;
+typedef const __attribute__((address_space(1))) f32x4u* gf4ptr;
+
+template <class CFG, int K0, int K1 = -1, int K2 = -1, int K3 = -1, int K4 = -1>
+__global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args) {
+    constexpr int KS[6] = {K0, K1, K2, K3, K4, -1};
+    constexpr int NSEG = K1 < 0 ? 1 : K2 < 0 ? 2 : K3 < 0 ? 3 : K4 < 0 ? 4 : 5;
+    constexpr int BM = CFG::BM, BN = CFG::BN, BK = MF_BK, P = MF_P, DEPTH = CFG::DEPTH, BML = CFG::BM_LDS;
+    constexpr int WTM = BM / CFG::WGM, WTN = BN / CFG::WGN, WM = WTM / 16, WN = WTN / 16, NSUB = BK / 8, NMF = 2 * WM * WN;
+    static_assert(CFG::WGM * CFG::WGN == 4 && WTM % 16 == 0 && WTN % 16 == 0 && BN % 32 == 0 && NSUB == 4, "tile");
+    // f32x4 per thread and k-step: thread t owns column quad t & 7 of tile rows (t >> 3) + 32 i
+    constexpr int NA = BML / 32, NB = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float mf_smem[];
+    float* const lds_a = mf_smem;                       // [2][BML][P]
+    float* const lds_b = mf_smem + 2 * BML * P;         // [2][BN][P]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int wm0 = (wave / CFG::WGN) * WTM, wn0 = (wave % CFG::WGN) * WTN;
+    const int M = args.M, N = args.N;
+    // XCD-aware order: workgroup ids are dealt round-robin over the 8 XCDs (id % 8); the column tiles of one row tile stream
+    // the same operand rows (gathered features, logits), so they get consecutive ids ON ONE XCD: one HBM fetch, L2 hits after
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int id = blockIdx.x, xcd = id & 7, local = id >> 3;
+    const int tn = local % tiles_n, tm = (local / tiles_n) * 8 + xcd;
+    if (tm >= tiles_m) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int quad = tid & 7, trow = tid >> 3;
+    unsigned long long* const stamps = args.stamps ? args.stamps + (size_t)blockIdx.x * 16 : nullptr;
+    auto stamp = [&](int slot) __attribute__((always_inline)) {
+        if (stamps && tid == 0) stamps[slot] = __builtin_readcyclecounter();
+    };
+    if (stamps && tid == 0) { stamps[14] = __builtin_amdgcn_s_memrealtime(); stamps[13] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20); }   // XCC_ID
+    stamp(0);
+
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // afB / bfB always hold the fragments of a sub-step whose MFMAs have not been issued yet (zeros at the start)
+    f32x2 afA[WM], bfA[WN], afB[WM], bfB[WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) afB[i] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < WN; ++j) bfB[j] = f32x2{0.f, 0.f};
+
+    auto read_frags = [&](int buf, int s, f32x2 (&af)[WM], f32x2 (&bf)[WN]) __attribute__((always_inline)) {
+        const float* a = lds_a + buf * BML * P + (wm0 + li) * P + 8 * s + 2 * lk;
+        const float* b = lds_b + buf * BN * P + (wn0 + li) * P + 8 * s + 2 * lk;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) af[i] = *(const f32x2*)(a + i * 16 * P);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bf[j] = *(const f32x2*)(b + j * 16 * P);
+    };
+    // k order inside a 32-deep step: MFMA (s, e) takes k = 8 s + 2 lk + e from lane group lk, for BOTH operands
+    auto mfma = [&](const f32x2 (&af)[WM], const f32x2 (&bf)[WN]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+    };
+
+    // Global-load register sets and operand pointers of the segment being loaded (shared by all segments).
+    f32x4 va[DEPTH][NA], vm[DEPTH][NA], vb[DEPTH][NB];
+    gfptr pa[NA]; gfptr pm[NA]; gfptr pb[NB]; float lse[NA];
+    auto setup = [&](auto kind_c, const MainSeg& g) __attribute__((always_inline)) {
+        constexpr int KIND = decltype(kind_c)::value;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int r = min(m0 + min(trow + 32 * i, BM - 1), M - 1);          // (rows beyond the tile / the matrix: clamped, never stored)
+            constexpr bool GAT = KIND == MK_GATHER || KIND == MK_GATHER_MUL;
+            const long long row = GAT ? (long long)((giptr)g.idx)[r] : (long long)r;
+            pa[i] = (gfptr)g.a + row * g.lda;
+            pm[i] = KIND == MK_GATHER_MUL ? (gfptr)g.a + (long long)((giptr)g.idx2)[r] * g.lda : pa[i];
+            lse[i] = KIND == MK_SOFTMAX ? ((gfptr)g.lse)[r] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) pb[i] = (gfptr)g.b + (long long)min(n0 + trow + 32 * i, N - 1) * g.ldb;
+    };
+    // tile t of a segment -> register set S.  Operand side: 16-byte windows slid left to stay inside [0, klen) (klen % 4 == 0:
+    // a window is either the true one or entirely beyond the extent, where the zero-padded weights null it); weight side:
+    // padded rows, read as they are.  Tiles beyond the segment re-load its last tile and are never stored.
+    auto issue = [&](auto set_c, auto mul_c, int klen, int nst, int t) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_c)::value;
+        const int ck = min(t, nst - 1) * BK + 4 * quad;
+        const int ca = min(ck, klen - 4);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) va[S][i] = *(gf4ptr)(pa[i] + ca);
+        if (decltype(mul_c)::value) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) vm[S][i] = *(gf4ptr)(pm[i] + ca);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) vb[S][i] = *(gf4ptr)(pb[i] + ck);
+    };
+    typedef IntC<0> S0; typedef IntC<DEPTH - 1> S1;
+    typedef std::true_type Tt; typedef std::false_type Ff;
+
+    // ---- one segment: its k-steps through the load pipeline ----------------------------------------------------------
+    // On entry tiles 0 .. DEPTH-1 of the segment are in flight in register sets 0 .. DEPTH-1 and `pa/pm/pb/lse` are its pointers.
+    auto run_seg = [&](auto idx_c) __attribute__((always_inline)) {
+        constexpr int I = decltype(idx_c)::value;
+        constexpr int KIND = KS[I], NKIND = KS[I + 1];                      // NKIND < 0: last segment
+        constexpr int LKIND = KIND == MK_GATHER_MUL ? LK_MUL : KIND == MK_SOFTMAX ? LK_SOFTMAX : LK_PLAIN;
+        typedef std::integral_constant<bool, LKIND == LK_MUL> MULC;
+        const MainSeg& sg = args.seg[I];
+        const int klen = sg.klen;
+        const int nst = (klen + BK - 1) / BK;
+        float lse_c[NA];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) lse_c[i] = lse[i];
+        // transform + LDS store of the tile in register set S; items [h0, h1)
+        auto stash = [&](auto set_c, int buf, int h0, int h1) __attribute__((always_inline)) {
+            constexpr int S = decltype(set_c)::value;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                if (i < h0 || i >= h1) continue;
+                f32x4 v = va[S][i];
+                if (LKIND == LK_MUL) v = v * vm[S][i];
+                if (LKIND == LK_SOFTMAX) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[j], 1.44269504088896341f, -lse_c[i]));
+                }
+                *(f32x4*)(lds_a + buf * BML * P + (trow + 32 * i) * P + 4 * quad) = v;       // (rows >= BM: spare LDS rows, never read)
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                if (i + NA < h0 || i + NA >= h1) continue;
+                *(f32x4*)(lds_b + buf * BN * P + (trow + 32 * i) * P + 4 * quad) = vb[S][i];
+            }
+        };
+        // prologue: tile 0 -> LDS buffer 0 (DEPTH 2: tile 2 into the freed set)
+        stash(S0{}, 0, 0, NA + NB);
+        issue(S0{}, MULC{}, klen, nst, DEPTH);
+        __syncthreads();
+
+        // step t (parity PAR = t & 1): LDS buffer PAR holds tile t; DEPTH 2: set PAR^1 holds tile t+1, set PAR tile t+2;
+        // DEPTH 1: the one set holds tile t+1 and is re-issued for tile t+2 once stored.
+        // LAST: nothing to store; the free register sets take the next segment's first tiles instead.
+        auto step = [&](auto par_c, auto last_c, int t) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_c)::value;
+            constexpr bool LAST = decltype(last_c)::value;
+            typedef IntC<DEPTH == 2 ? (PAR ^ 1) : 0> SS;
+            read_frags(PAR, 0, afA, bfA);
+            mfma(afB, bfB);                                              // (t-1, last sub-step): covers the reads above
+#pragma unroll
+            for (int q = 0; q < NMF; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+            if (LAST && NKIND >= 0) {
+                const MainSeg& nx = args.seg[I + 1 < MAIN_MAX_SEG ? I + 1 : I];
+                setup(IntC<NKIND>{}, nx);
+                const int kn = nx.klen, nn = (kn + BK - 1) / BK;
+                typedef std::integral_constant<bool, NKIND == MK_GATHER_MUL> NM;
+                issue(S0{}, NM{}, kn, nn, 0);
+                if (DEPTH == 2) issue(S1{}, NM{}, kn, nn, 1);
+            }
+#pragma unroll
+            for (int s = 0; s < NSUB - 1; ++s) {
+                auto& afc = (s & 1) ? afB : afA; auto& bfc = (s & 1) ? bfB : bfA;
+                auto& afn = (s & 1) ? afA : afB; auto& bfn = (s & 1) ? bfA : bfB;
+                read_frags(PAR, s + 1, afn, bfn);
+                if (!LAST) {
+                    if (s == 0) stash(SS{}, PAR ^ 1, 0, (NA + NB) / 2);
+                    if (s == 1) stash(SS{}, PAR ^ 1, (NA + NB) / 2, NA + NB);
+                    if (s == 2) issue(SS{}, MULC{}, klen, nst, t + 1 + DEPTH);
+                }
+                mfma(afc, bfc);
+#pragma unroll
+                for (int q = 0; q < NMF; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        };
+        typedef IntC<0> P0; typedef IntC<1> P1;
+        int t = 0;
+        for (; t + 2 < nst; t += 2) { step(P0{}, Ff{}, t); step(P1{}, Ff{}, t + 1); }            // t + 1 <= nst - 2
+        if (t + 1 < nst) { step(P0{}, Ff{}, t); step(P1{}, Tt{}, t + 1); }
+        else step(P0{}, Tt{}, t);
+    };
+
+    setup(IntC<K0>{}, args.seg[0]);
+    {
+        const MainSeg& g = args.seg[0];
+        const int nn = (g.klen + BK - 1) / BK;
+        typedef std::integral_constant<bool, K0 == MK_GATHER_MUL> M0;
+        issue(S0{}, M0{}, g.klen, nn, 0);
+        if (DEPTH == 2) issue(S1{}, M0{}, g.klen, nn, 1);
+    }
+    run_seg(IntC<0>{}); stamp(1);
+    if constexpr (NSEG > 1) { run_seg(IntC<1>{}); stamp(2); }
+    if constexpr (NSEG > 2) { run_seg(IntC<2>{}); stamp(3); }
+    if constexpr (NSEG > 3) { run_seg(IntC<3>{}); stamp(4); }
+    if constexpr (NSEG > 4) { run_seg(IntC<4>{}); stamp(5); }
+    mfma(afB, bfB);                                      // the last sub-step of the last segment
+
+    // ---- epilogue: + Sh[r / K] (+ bias), ReLU, Dropout, store ---------------------------------------------------------
+    // Every operand is fetched behind one uniform test per kind (a test per element puts each load in its own basic block:
+    // 24 serialised round trips); r / K of a lane's 4 consecutive rows comes from ONE division.
+    const EpiArgs& e = args.epi;
+    const int rdiv = e.rowadd ? e.rowdiv : 1;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        float addv[WN][4], maskv[WN][4], gatev[WN][4], bias_v[WN];
+        int nc[WN];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) nc[j] = min(n0 + wn0 + 16 * j + li, N - 1);
+        const int rb = m0 + wm0 + 16 * i + 4 * lk;                     // first of this lane's 4 rows
+        const int q0 = rb / rdiv, rem0 = rb - q0 * rdiv;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            bias_v[j] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { addv[j][q] = 0.f; maskv[j][q] = 1.f; gatev[j][q] = 1.f; }
+        }
+        if (e.bias) {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bias_v[j] = e.bias[nc[j]];
+        }
+        if (e.rowadd) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = rem0 + q;                                  // < rdiv + 3: at most one wrap (rdiv >= 3)
+                const int bq = min(q0 + (t >= rdiv ? 1 : 0), (M - 1) / rdiv);
+#pragma unroll
+                for (int j = 0; j < WN; ++j) addv[j][q] = e.rowadd[(long long)bq * e.ld_rowadd + nc[j]];
+            }
+        }
+        if (e.dropout == 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) maskv[j][q] = e.keep_mask[(long long)min(rb + q, M - 1) * e.ld_mask + nc[j]];
+        }
+        if (e.gate) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) gatev[j][q] = e.gate[(long long)min(rb + q, M - 1) * e.ld_gate + nc[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int n = n0 + wn0 + 16 * j + li;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = rb + q;
+                float v = acc[i][j][q] + addv[j][q] + bias_v[j];
+                if (e.relu == 1) v = v > 0.f ? v : 0.f;
+                else if (e.relu == 2) v = tanhf(v);
+                if (e.dropout == 1)
+                    v = dropout_keep(e.seed_lo, e.seed_hi, e.layer, (unsigned long long)r * (unsigned)N + (unsigned)n, e.drop_p) ? v * e.drop_scale : 0.f;
+                else if (e.dropout == 2)
+                    v = maskv[j][q] != 0.f ? v * e.drop_scale : 0.f;
+                if (e.gate) v = gatev[j][q] > 0.f ? v * e.gate_scale : 0.f;
+                if (r < M && n < N) args.out[(long long)r * args.ldo + n] = v;
+            }
+        }
+    }
+    stamp(8);
+    if (stamps && tid == 0) stamps[15] = __builtin_amdgcn_s_memrealtime();
+}
+
+// Operand requirements of the kernel (see the header comment): klen >= 4 and a multiple of 4; weight rows readable (zero
+// padded) up to the next multiple of 32 columns.
+static inline bool main_fwd_operand_ok(int klen) { return klen >= 4 && klen % 4 == 0; }
+
+template <class CFG, int... KINDS>
+static inline int launch_main_fwd_seq(MainArgs& a, hipStream_t s) {
+    static bool attr = false;
+    if (!attr) { NCX_HIP_TRY(hipFuncSetAttribute((const void*)k_main_fwd<CFG, KINDS...>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS)); attr = true; }
+    const int tiles_m = (a.M + CFG::BM - 1) / CFG::BM, tiles_n = (a.N + CFG::BN - 1) / CFG::BN;
+    const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
+    hipLaunchKernelGGL((k_main_fwd<CFG, KINDS...>), dim3(grid), dim3(MF_T), CFG::LDS, s, a);
+    NCX_HIP_TRY(hipGetLastError());
+    return NCX_OK;
+}
+
+// The five operand-kind sequences the library uses (anything else: NCX_E_FLAGS).
+template <class CFG>
+static inline int launch_main_fwd(MainArgs& a, hipStream_t s) {
+    if (a.nseg < 1 || a.nseg > MAIN_MAX_SEG || a.M < 1 || a.N < 1) return NCX_E_DIMS;
+    for (int i = 0; i < a.nseg; ++i) if (!main_fwd_operand_ok(a.seg[i].klen)) return NCX_E_DIMS;
+    if (a.epi.rowadd && a.epi.rowdiv < 3) return NCX_E_DIMS;                        // (the epilogue's row -> triplet map assumes K >= 3)
+    auto is = [&](std::initializer_list<int> ks) { if ((int)ks.size() != a.nseg) return false; int i = 0; for (int k : ks) if (a.seg[i++].kind != k) return false; return true; };
+    constexpr int G = MK_GATHER, X = MK_GATHER_MUL, P = MK_PLAIN, S = MK_SOFTMAX;
+    if (is({G, X, P, P, S})) return launch_main_fwd_seq<CFG, G, X, P, P, S>(a, s);
+    if (is({P}))             return launch_main_fwd_seq<CFG, P>(a, s);
+    if (is({G, P, P, S}))    return launch_main_fwd_seq<CFG, G, P, P, S>(a, s);
+    if (is({G, X, P, P, P})) return launch_main_fwd_seq<CFG, G, X, P, P, P>(a, s);
+    if (is({G, P, P, P}))    return launch_main_fwd_seq<CFG, G, P, P, P>(a, s);
+    return NCX_E_FLAGS;
+}
+
+}  // namespace ncx
