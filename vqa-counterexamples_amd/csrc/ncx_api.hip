@@ -39,6 +39,39 @@ __device__ __forceinline__ void store_bf16x4(u16* p, const float (&v)[4], int va
     else { for (int j = 0; j < valid; ++j) p[j] = f32_to_bf16(v[j]); }
 }
 
+// Padded weight copies (ncx_main.h reads every weight row up to the next multiple of 32 columns).  Slot i of the wpad region:
+//   0 v_other  1 v_mult  2 dist | rank  3 z_other  4 a_other (a_emb lesion only)  5 linear_2  6 linear_3
+// width 0: the slice is used in place (already a multiple of 32 wide, or the segment does not exist).
+constexpr int WPAD_N = 7;
+static inline int wpad_cols(const ncx_dims& d, int i) {
+    switch (i) {
+    case 0: return d.dv;
+    case 1: return (d.flags & NCX_F_V_MULT) ? d.dv : 0;
+    case 2: return d.K + 1;
+    case 3: return d.dz;
+    case 4: return (d.flags & NCX_F_A_EMB) ? 0 : d.da;
+    case 5: return d.L >= 2 ? d.H : 0;
+    default: return d.L >= 3 ? d.H : 0;
+    }
+}
+static inline int wpad_width(const ncx_dims& d, int i) {
+    const int c = wpad_cols(d, i);
+    if (d.flags & NCX_F_BF16) return 0;
+    return (c == 0 || c % 32 == 0) ? 0 : pad_to(c, 32);
+}
+struct PackArgs { const float* src[WPAD_N + 1]; float* dst[WPAD_N + 1]; long long lds[WPAD_N + 1]; int cols[WPAD_N + 1], ldd[WPAD_N + 1], zero_from[WPAD_N + 1]; int n, H; };
+// dst[e][h][0 .. cols) = src[e][h][0 .. cols);  dst[e][h][zero_from .. ldd) = 0.   One block per (h, e): H * n blocks, which
+// ride at the end of k_prep's grid (a launch of their own cost 5 us for 0.5 MB of copies).
+__device__ __forceinline__ void pack_rows_block(const PackArgs& a, int idx) {
+    const int h = idx % a.H, e = idx / a.H;
+    float* drow = a.dst[e] + (long long)h * a.ldd[e];
+    if (a.src[e]) {
+        const float* srow = a.src[e] + (long long)h * a.lds[e];
+        for (int c = threadIdx.x; c < a.cols[e]; c += 256) drow[c] = srow[c];
+    }
+    for (int c = a.zero_from[e] + threadIdx.x; c < a.ldd[e]; c += 256) drow[c] = 0.f;
+}
+
 // One wave per candidate row.  Rows of up to 2048 floats (the real widths: 2048-d features, 2000 answers) are read from
 // memory ONCE into registers (8 x float4 per lane) and every pass -- distance, max, sum, bf16 pack -- runs on the
 // registers; wider rows (RESIDENT = false) re-read them from memory per pass.  Same per-lane element order and the same
@@ -47,11 +80,13 @@ template <bool RESIDENT>
 __global__ __launch_bounds__(256) void k_prep(ncx_dims d, ncx_inputs in, int* __restrict__ idx_k,
                                               int* __restrict__ idx_o, int* __restrict__ idx_ob,
                                               float* __restrict__ mx, float* __restrict__ inv,
-                                              float* __restrict__ misc, u16* __restrict__ xc, Bf16Cols cc) {
+                                              float* __restrict__ misc, u16* __restrict__ xc, Bf16Cols cc, const PackArgs pk) {
     constexpr int NR = RESIDENT ? 8 : 1;
     const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int M = d.B * d.K;
+    const int nprep = (M + 3) / 4;
+    if ((int)blockIdx.x >= nprep) { pack_rows_block(pk, (int)blockIdx.x - nprep); return; }     // the weight-pack blocks
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
     const int b = r / d.K, k = r - b * d.K;
     const int io = in.img_idx[(long long)b * (d.K + 1)];
@@ -339,8 +374,15 @@ __global__ __launch_bounds__(256) void k_bwd_prelude(const float* __restrict__ g
                                                      const float* __restrict__ h, float* __restrict__ dpre,
                                                      float* __restrict__ dsh, int B, int K, int H, float scale,
                                                      float* __restrict__ partial_w, float* __restrict__ partial_b1,
-                                                     float* __restrict__ partial_b) {
+                                                     float* __restrict__ partial_b, float* __restrict__ zero_buf, long long zero_n) {
     const int blk = blockIdx.x, nblk = gridDim.x;
+    if (zero_buf) {          // dGgt = one-hot(aid)^T dSh is scattered into zeros later in the backward: cleared here (saves a memset launch)
+        const long long z0 = zero_n * blk / nblk / 4 * 4, z1 = blk + 1 == nblk ? zero_n : zero_n * (blk + 1) / nblk / 4 * 4;
+        for (long long i = z0 + 4 * threadIdx.x; i < z1; i += 1024) {
+            if (i + 3 < z1) *(f32x4u*)(zero_buf + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+            else for (long long j = i; j < z1; ++j) zero_buf[j] = 0.f;
+        }
+    }
     const int b0 = (int)((long long)B * blk / nblk), b1 = (int)((long long)B * (blk + 1) / nblk);
     for (int n = threadIdx.x; n < H; n += 256) {
         const float w = w_out[n];
@@ -479,38 +521,6 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
             }
         }
     }
-}
-
-// Padded weight copies (ncx_main.h reads every weight row up to the next multiple of 32 columns).  Slot i of the wpad region:
-//   0 v_other  1 v_mult  2 dist | rank  3 z_other  4 a_other (a_emb lesion only)  5 linear_2  6 linear_3
-// width 0: the slice is used in place (already a multiple of 32 wide, or the segment does not exist).
-constexpr int WPAD_N = 7;
-static inline int wpad_cols(const ncx_dims& d, int i) {
-    switch (i) {
-    case 0: return d.dv;
-    case 1: return (d.flags & NCX_F_V_MULT) ? d.dv : 0;
-    case 2: return d.K + 1;
-    case 3: return d.dz;
-    case 4: return (d.flags & NCX_F_A_EMB) ? 0 : d.da;
-    case 5: return d.L >= 2 ? d.H : 0;
-    default: return d.L >= 3 ? d.H : 0;
-    }
-}
-static inline int wpad_width(const ncx_dims& d, int i) {
-    const int c = wpad_cols(d, i);
-    if (d.flags & NCX_F_BF16) return 0;
-    return (c == 0 || c % 32 == 0) ? 0 : pad_to(c, 32);
-}
-struct PackArgs { const float* src[WPAD_N + 1]; float* dst[WPAD_N + 1]; long long lds[WPAD_N + 1]; int cols[WPAD_N + 1], ldd[WPAD_N + 1], zero_from[WPAD_N + 1]; int n, H; };
-// dst[e][h][0 .. cols) = src[e][h][0 .. cols);  dst[e][h][zero_from .. ldd) = 0.   grid (H, n)
-__global__ __launch_bounds__(256) void k_pack_rows(const PackArgs a) {
-    const int h = blockIdx.x, e = blockIdx.y;
-    float* drow = a.dst[e] + (long long)h * a.ldd[e];
-    if (a.src[e]) {
-        const float* srow = a.src[e] + (long long)h * a.lds[e];
-        for (int c = threadIdx.x; c < a.cols[e]; c += 256) drow[c] = srow[c];
-    }
-    for (int c = a.zero_from[e] + threadIdx.x; c < a.ldd[e]; c += 256) drow[c] = 0.f;
 }
 
 // =================================================================================================
@@ -907,20 +917,12 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
     if (ss) { rc = side_fork(ss, s); if (rc) return rc; }
     const bool bf16 = d.flags & NCX_F_BF16;
     u16* xc = bf16 ? (u16*)(ws + w.xc) : nullptr;
-    if (d.dv <= 2048 && d.A <= 2048)
-        hipLaunchKernelGGL(k_prep<true>, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, s, d, *in, idx_k, idx_o, idx_ob, mx, inv, misc, xc,
-                           bf16_cols(d));
-    else
-        hipLaunchKernelGGL(k_prep<false>, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, s, d, *in, idx_k, idx_o, idx_ob, mx, inv, misc, xc,
-                           bf16_cols(d));
-    NCX_HIP_TRY(hipGetLastError());
-
     // zero-padded copies of the weight slices the fused forward kernel reads past their width (+ the pad columns of Gt):
     // functions of the weights only, like Gt -- evaluation passes reuse them (NCX_F_REUSE_GT)
     struct { const float* ptr[WPAD_N]; int width[WPAD_N]; } wp{};
+    PackArgs pk{}; pk.H = H;
     {
         const float* srcs[WPAD_N] = {p->w1 + o.v_other, p->w1 + o.v_mult, p->w1 + o.v_dist, p->w1 + o.z_other, p->w1 + o.a_other, p->w2, p->w3};
-        PackArgs pk{}; pk.H = H;
         float* cur = (float*)(ws + w.wpad);
         for (int i = 0; i < WPAD_N; ++i) {
             wp.width[i] = wpad_width(d, i); wp.ptr[i] = cur;
@@ -930,11 +932,15 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
             cur += (size_t)H * wp.width[i];
         }
         if (aemb && w.ldgt > d.A) { const int e = pk.n++; pk.src[e] = nullptr; pk.dst[e] = gt; pk.ldd[e] = w.ldgt; pk.zero_from[e] = d.A; pk.cols[e] = 0; }
-        if (pk.n && !(d.flags & NCX_F_REUSE_GT)) {
-            hipLaunchKernelGGL(k_pack_rows, dim3(H, pk.n), dim3(256), 0, s, pk);
-            NCX_HIP_TRY(hipGetLastError());
-        }
+        if (d.flags & NCX_F_REUSE_GT) pk.n = 0;
     }
+    const unsigned prep_grid = (unsigned)(cdiv(M, 4) + (long long)H * pk.n);
+    if (d.dv <= 2048 && d.A <= 2048)
+        hipLaunchKernelGGL(k_prep<true>, dim3(prep_grid), dim3(256), 0, s, d, *in, idx_k, idx_o, idx_ob, mx, inv, misc, xc, bf16_cols(d), pk);
+    else
+        hipLaunchKernelGGL(k_prep<false>, dim3(prep_grid), dim3(256), 0, s, d, *in, idx_k, idx_o, idx_ob, mx, inv, misc, xc, bf16_cols(d), pk);
+    NCX_HIP_TRY(hipGetLastError());
+
     // Gt[H, A] = W1[:, a_other] . E^T   (weights only: evaluation passes reuse it, NCX_F_REUSE_GT)
     if (aemb && bf16 && !(d.flags & NCX_F_REUSE_GT)) {       // bf16 copies of E / W1[:, a_*] (also the backward's operands)
         const Bf16Emb m = bf16_emb_layout(d, ws + w.bf_emb);
@@ -1130,7 +1136,7 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
         float* part_b = partial + (size_t)NCX_COLSUM_CHUNKS * H * 2;
         const bool fuse_l1 = d.L == 1;
         hipLaunchKernelGGL(k_bwd_prelude, dim3(nblk), dim3(256), 0, s, dscores, p->w_out, hL, dpre, fuse_l1 ? dsh : (float*)nullptr,
-                           d.B, d.K, H, dscale, part_w, part_b1, part_b);
+                           d.B, d.K, H, dscale, part_w, part_b1, part_b, aemb ? dagt : (float*)nullptr, (long long)H * d.A);
         NCX_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_bwd_prelude_finish, dim3((unsigned)cdiv(H, 8), fuse_l1 ? 2 : 1), dim3(256), 0, s, (const float*)part_w,
                            (const float*)part_b1, (const float*)part_b, nblk, H, g->w_out, fuse_l1 ? g->b1 : (float*)nullptr, g->b_out);
@@ -1236,8 +1242,7 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
             rc = run_gemm(U_DW1AK, a, FORM_NN, u[U_DW1AK].plan, ss ? (float*)(ws + w.slab2) : slab,
                           ss ? w.slab2_bytes : w.slab_bytes, nullptr, ss ? ss->s : s); if (rc) return rc;
         }
-        if (do1) {   // dGgt = one-hot(aid)^T dSh
-            NCX_HIP_TRY(hipMemsetAsync(dagt, 0, (size_t)H * d.A * 4, s));
+        if (do1) {   // dGgt = one-hot(aid)^T dSh   (dGgt was cleared by k_bwd_prelude)
             hipLaunchKernelGGL(k_scatter_dsh_by_answer, dim3(d.B), dim3(256), 0, s, (const float*)dsh, in->answer_aids, d.B, H, d.A, dagt);
             NCX_HIP_TRY(hipGetLastError());
         }
