@@ -42,7 +42,7 @@ static float time_cfg(const char* name, const Problem& p, unsigned segmask, cons
         maxdiff = 0; for (size_t i = 0; i < nn; ++i) { double d = fabs((double)h[i] - r[i]); if (!(d <= maxdiff)) maxdiff = d; }
     }
     const double gf = 2.0 * a.M * a.N * cols * 1e-9;
-    int occ = 0; CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_main_fwd<CFG, MK_GATHER, MK_GATHER_MUL, MK_PLAIN, MK_PLAIN, MK_SOFTMAX>, MF_T, CFG::LDS));
+    int occ = 0; CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_main_fwd<CFG, false, MK_GATHER, MK_GATHER_MUL, MK_PLAIN, MK_PLAIN, MK_SOFTMAX>, MF_T, CFG::LDS));
     if (print) printf("%-22s segs %02x  ksteps %4.0f  avg %7.1f us  best %7.1f  %6.1f TF  (%.3f us/kstep)  occ %d  maxdiff %.2e\n", name, segmask, ksteps,
                       tot / reps * 1e3, best * 1e3, gf / (tot / reps), tot / reps * 1e3 / ksteps, occ, maxdiff);
     fflush(stdout);
@@ -130,6 +130,9 @@ int main(int argc, char** argv) {
         add("dense 1 segment 64x64 d2 o3", [&] { MainArgs a = pd.full; launch_main_fwd<C_64_64_d2_o3>(a, 0); });
         add("real            64x64 d2 o3", [&] { MainArgs a = p.full; launch_main_fwd<C_64_64_d2_o3>(a, 0); });
         add("real            96x128 d2 o1", [&] { MainArgs a = p.full; launch_main_fwd<C_96_128_d2_o1>(a, 0); });
+        float* dist_buf; CHECK(hipMalloc(&dist_buf, (size_t)M * 28 * 4));
+        add("real + in-kernel dist 96x128 d2 o1", [&] { MainArgs a = p.full; a.dist_out = dist_buf; a.ld_dist = 28; launch_main_fwd<C_96_128_d2_o1>(a, 0); });
+        add("real + in-kernel dist 48x128 d2", [&] { MainArgs a = p.full; a.dist_out = dist_buf; a.ld_dist = 28; launch_main_fwd<CB>(a, 0); });
         hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
         for (int round = 0; round < 7; ++round)
             for (auto& v : vs) {

@@ -95,7 +95,8 @@ __global__ __launch_bounds__(256) void k_prep(ncx_dims d, ncx_inputs in, int* __
     const float* vo = in.feats + (long long)io * d.dv;
     const float* vk = in.feats + (long long)ik * d.dv;
     u16* xr = xc ? xc + (long long)r * cc.kc : nullptr;
-    const bool need_v = (d.flags & NCX_F_V_DIST) || xc;
+    const bool own_dist = (d.flags & NCX_F_V_DIST) && !(d.flags & NCX_F_PRIV_DIST_IN_MAIN);
+    const bool need_v = own_dist || xc;
 
     f32x4 ro[NR], rk[NR];
     if (RESIDENT && need_v) {
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256) void k_prep(ncx_dims d, ncx_inputs in, int* __
         if (RESIDENT) { a = ro[i]; e = rk[i]; } else { a = load4(vo, c, d.dv); e = load4(vk, c, d.dv); }
     };
     float dist = 0.f;
-    if (d.flags & NCX_F_V_DIST) {
+    if (own_dist) {
         float s = 0.f;
         if (RESIDENT) {
 #pragma unroll
@@ -740,6 +741,14 @@ WsLayout ws_layout(const ncx_dims& d) {
         w.slab2 = take(w.slab2_bytes);
     }
     w.km_slab = take(dw_km_slab_bytes(d));
+    {   // split-K slabs of the fused forward kernel: linear_1 / hidden layers at small batches
+        const long long Tm = ks(d.dv) * ((d.flags & NCX_F_V_MULT) ? 2 : 1) + ks(pad_to(d.K + 1, 4)) + ks(d.dz) + ((d.flags & NCX_F_A_EMB) ? ks(d.A) : ks(d.da));
+        auto need = [&](long long m, long long n, long long t) { const int sp = main_split(m, n, t); return sp > 1 ? (size_t)sp * m * n * 4 : (size_t)0; };
+        size_t b = need((long long)M, (long long)H, Tm);
+        if (d.L >= 2) b = b > need((long long)M, (long long)H, ks(H)) ? b : need((long long)M, (long long)H, ks(H));
+        w.mslab_bytes = b;
+        w.mslab = take(b);
+    }
     {   // padded weight copies for the fused forward kernel: [H][pad32(width)] each, in the order pack_wpad fills them
         size_t e = 0;
         for (int i = 0; i < WPAD_N; ++i) e += (size_t)H * wpad_width(d, i);
@@ -797,6 +806,7 @@ static int check_dims(const ncx_dims* d) {
     if ((long long)d->B * d->K > (1ll << 30) / 4 || d->B > NCX_SCATTER_MAX_B) return NCX_E_DIMS;
     if (d->dv < 4 || d->dq < 4 || d->dz < 4 || d->da < 4 || d->A < 4 || d->H < 4 || d->K < 3) return NCX_E_DIMS;   // 16-byte windows
     if (d->drop_p < 0.f || d->drop_p >= 1.f) return NCX_E_DIMS;
+    if (d->flags & ~(NCX_F_ALL | NCX_F_BF16 | NCX_F_REUSE_GT)) return NCX_E_FLAGS;
     if ((d->flags & NCX_F_BF16) && (d->flags & NCX_F_ALL) != NCX_F_ALL) return NCX_E_FLAGS;    // bf16 variant: no lesions
     return NCX_OK;
 }
@@ -928,17 +938,23 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
             wp.width[i] = wpad_width(d, i); wp.ptr[i] = cur;
             if (!wp.width[i]) continue;
             const int e = pk.n++;
-            pk.src[e] = srcs[i]; pk.lds[e] = i >= 5 ? H : din; pk.cols[e] = wpad_cols(d, i); pk.dst[e] = cur; pk.ldd[e] = wp.width[i]; pk.zero_from[e] = pk.cols[e];
+            pk.src[e] = srcs[i]; pk.lds[e] = (i == 5 || i == 6) ? H : din; pk.cols[e] = wpad_cols(d, i); pk.dst[e] = cur; pk.ldd[e] = wp.width[i]; pk.zero_from[e] = pk.cols[e];
             cur += (size_t)H * wp.width[i];
         }
         if (aemb && w.ldgt > d.A) { const int e = pk.n++; pk.src[e] = nullptr; pk.dst[e] = gt; pk.ldd[e] = w.ldgt; pk.zero_from[e] = d.A; pk.cols[e] = 0; }
         if (d.flags & NCX_F_REUSE_GT) pk.n = 0;
     }
+    // the pairwise distance rides in the fused forward kernel when that kernel sees whole v rows (no k-split, no slid windows)
+    long long main_T = ks(d.dv) * ((d.flags & NCX_F_V_MULT) ? 2 : 1) + ks(w.ldm) + ks(d.dz) + (aemb ? ks(d.A) : ks(d.da));
+    const bool dist_in_main = main_fwd_dims_ok(d) && (d.flags & NCX_F_V_DIST) && (d.flags & NCX_F_V_MULT) && d.dv % 32 == 0 &&
+                              main_split(M, H, main_T) == 1 && !(hook_env("NCX_NO_DIST_IN_MAIN"));
+    ncx_dims dprep = d;
+    if (dist_in_main) dprep.flags |= NCX_F_PRIV_DIST_IN_MAIN;
     const unsigned prep_grid = (unsigned)(cdiv(M, 4) + (long long)H * pk.n);
     if (d.dv <= 2048 && d.A <= 2048)
-        hipLaunchKernelGGL(k_prep<true>, dim3(prep_grid), dim3(256), 0, s, d, *in, idx_k, idx_o, idx_ob, mx, inv, misc, xc, bf16_cols(d), pk);
+        hipLaunchKernelGGL(k_prep<true>, dim3(prep_grid), dim3(256), 0, s, dprep, *in, idx_k, idx_o, idx_ob, mx, inv, misc, xc, bf16_cols(d), pk);
     else
-        hipLaunchKernelGGL(k_prep<false>, dim3(prep_grid), dim3(256), 0, s, d, *in, idx_k, idx_o, idx_ob, mx, inv, misc, xc, bf16_cols(d), pk);
+        hipLaunchKernelGGL(k_prep<false>, dim3(prep_grid), dim3(256), 0, s, dprep, *in, idx_k, idx_o, idx_ob, mx, inv, misc, xc, bf16_cols(d), pk);
     NCX_HIP_TRY(hipGetLastError());
 
     // Gt[H, A] = W1[:, a_other] . E^T   (weights only: evaluation passes reuse it, NCX_F_REUSE_GT)
@@ -997,6 +1013,12 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
         a.out = (float*)(ws + w.h[0]); a.ldo = H;
         a.epi.rowadd = sh; a.epi.ld_rowadd = H; a.epi.rowdiv = d.K;
         set_dropout(a.epi, d, *in, 1, M);
+        if (dist_in_main) { a.dist_out = misc; a.ld_dist = w.ldm; }
+        {
+            long long T = 0; for (int i = 0; i < n; ++i) T += ks(a.seg[i].klen);
+            a.split = main_split(M, H, T); a.slab = (float*)(ws + w.mslab);
+            if (a.split > 1 && (size_t)a.split * M * H * 4 > w.mslab_bytes) return NCX_E_WORKSPACE;
+        }
         rc = prof_open(U_MAIN, s); if (rc) return rc;
         rc = main_forward(a, s); if (rc) return rc;
         rc = prof_close(U_MAIN, s); if (rc) return rc;
@@ -1029,6 +1051,8 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
             a.out = (float*)(ws + w.h[l - 1]); a.ldo = H;
             a.epi.bias = bl;
             set_dropout(a.epi, d, *in, l, M);
+            a.split = main_split(M, H, ks(H)); a.slab = (float*)(ws + w.mslab);
+            if (a.split > 1 && (size_t)a.split * M * H * 4 > w.mslab_bytes) return NCX_E_WORKSPACE;
             rc = prof_open(U_FWD_L, s); if (rc) return rc;
             rc = main_forward(a, s); if (rc) return rc;
             rc = prof_close(U_FWD_L, s); if (rc) return rc;

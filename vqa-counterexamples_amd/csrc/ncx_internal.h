@@ -60,6 +60,7 @@ struct WsLayout {
     size_t xc, wc, dpre_bf, bf_slab;    // NCX_F_BF16: packed bf16 candidate rows / weights / dpre, k-chunk slabs of dWc
     size_t bf_emb;                      // NCX_F_BF16: bf16 images of E, E^T, [W1ak; W1agt], [dGt; dGgt]
     size_t km_slab;                     // k-chunk slabs of the fused v_other / v_mult weight gradient (ncx_dwkm.hip)
+    size_t mslab, mslab_bytes;          // [split][M][N] partial sums of the fused forward kernel's split problems (max over its uses)
     size_t wpad;                        // zero-padded copies of the weight slices whose width is not a multiple of 32 (ncx_main.h)
     int ldm;                            // leading dimension of misc: K + 1 rounded up to a multiple of 4 (zero padded)
     int ldgt;                           // leading dimension of Gt: A rounded up to a multiple of 32 (zero padded); bf16 variant: A
@@ -81,10 +82,19 @@ struct MainSeg {
     int kind, klen;      // klen: reduction extent (columns of the segment), >= 4
 };
 struct MainArgs {
-    MainSeg seg[MAIN_MAX_SEG]; int nseg, M, N, pad_; float* out; long long ldo; EpiArgs epi;
+    MainSeg seg[MAIN_MAX_SEG]; int nseg, M, N, split; float* out; long long ldo; EpiArgs epi;
+    float* slab;                     // split > 1: [split][M][N] partial sums
+    // dist_out != NULL (sequence G, X, P, ...; split == 1; v rows a multiple of 32 wide): the pairwise distance
+    // ||v_o - v_k + 1e-6|| (cx.py:300) is accumulated while the v_o * v_k segment streams both rows, patched into column 0 of
+    // the following (dist | rank) segment's first tile and stored to dist_out[r * ld_dist] for the backward pass -- k_prep then
+    // does not have to read the 200 MB of feature rows a second time
+    float* dist_out; long long ld_dist;
     unsigned long long* stamps;      // diagnostics (tools/mb/mb_main.hip): 16 words per workgroup of s_memtime / s_memrealtime stamps; NULL in the library
 };
 int main_forward(MainArgs& a, hipStream_t s);
+// k-split of a problem for the fused forward kernel (48 x 128 tiles): 1 when its tiles already give every CU a workgroup,
+// else as many k-chunks as keep all workgroups resident at once (two per CU), at least 8 k-steps each.  T: k-steps of the whole chain.
+int main_split(long long M, long long N, long long T);
 
 // ncx_dwkm.hip: d linear_1.weight[:, v_other] and [:, v_mult] in one MFMA pass with a per-triplet fold
 constexpr int DW_KM_SPLIT = 8;
@@ -100,5 +110,9 @@ static inline bool main_fwd_dims_ok(const ncx_dims& d) {
     return d.dv % 4 == 0 && d.dz % 4 == 0 && ((d.flags & NCX_F_A_EMB) ? d.A : d.da) % 4 == 0 && !(d.flags & NCX_F_BF16);
 }
 static inline bool hidden_fwd_dims_ok(const ncx_dims& d) { return d.H % 4 == 0; }
+// private flag bit (never set by callers: check_dims rejects it): the pairwise distance is computed inside the fused forward
+// kernel, k_prep leaves the feature rows alone
+constexpr uint32_t NCX_F_PRIV_DIST_IN_MAIN = 1u << 30;
+
 
 }  // namespace ncx

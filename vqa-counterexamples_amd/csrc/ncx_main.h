@@ -51,8 +51,9 @@ typedef const __attribute__((address_space(1))) float* gfptr;      // global add
 typedef const __attribute__((address_space(1))) int* giptr;
 typedef const __attribute__((address_space(1))) f32x4u* gf4ptr;
 
-template <class CFG, int K0, int K1 = -1, int K2 = -1, int K3 = -1, int K4 = -1>
+template <class CFG, bool DIST, int K0, int K1 = -1, int K2 = -1, int K3 = -1, int K4 = -1>
 __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args) {
+    static_assert(!DIST || (K1 == MK_GATHER_MUL && K2 == MK_PLAIN), "DIST: v_o * v_k segment followed by the dist | rank segment");
     constexpr int KS[6] = {K0, K1, K2, K3, K4, -1};
     constexpr int NSEG = K1 < 0 ? 1 : K2 < 0 ? 2 : K3 < 0 ? 3 : K4 < 0 ? 4 : 5;
     constexpr int BM = CFG::BM, BN = CFG::BN, BK = MF_BK, P = MF_P, DEPTH = CFG::DEPTH, BML = CFG::BM_LDS;
@@ -68,10 +69,16 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
     const int M = args.M, N = args.N;
     // XCD-aware order: workgroup ids are dealt round-robin over the 8 XCDs (id % 8); the column tiles of one row tile stream
     // the same operand rows (gathered features, logits), so they get consecutive ids ON ONE XCD: one HBM fetch, L2 hits after
+    // Split-K (args.split = S > 1: problems with too few tiles for 256 CUs -- small batches, the weight-only products): S
+    // workgroups share a tile, each takes a contiguous range of the k-steps of the WHOLE segment chain and stores its raw
+    // accumulators to slab[z][M][N]; k_main_fixup sums the S slabs in fixed order and applies the epilogue.
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int S = args.split > 1 ? args.split : 1;
+    // (row tile, k-chunk) units are dealt over the XCDs; the column tiles of a unit are consecutive ids on one XCD
     const int id = blockIdx.x, xcd = id & 7, local = id >> 3;
-    const int tn = local % tiles_n, tm = (local / tiles_n) * 8 + xcd;
-    if (tm >= tiles_m) return;
+    const int tn = local % tiles_n, unit = (local / tiles_n) * 8 + xcd;
+    if (unit >= tiles_m * S) return;
+    const int tm = unit / S, z = unit - tm * S;
     const int m0 = tm * BM, n0 = tn * BN;
     const int quad = tid & 7, trow = tid >> 3;
     unsigned long long* const stamps = args.stamps ? args.stamps + (size_t)blockIdx.x * 16 : nullptr;
@@ -111,9 +118,18 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
                 for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
     };
 
+    // this workgroup's range [g0, g1) of the chain's k-steps
+    int nsteps[MAIN_MAX_SEG], total_steps = 0;
+#pragma unroll
+    for (int i = 0; i < MAIN_MAX_SEG; ++i) { nsteps[i] = i < NSEG ? (args.seg[i].klen + BK - 1) / BK : 0; total_steps += nsteps[i]; }
+    const int g0 = (int)((long long)total_steps * z / S), g1 = (int)((long long)total_steps * (z + 1) / S);
+
     // Global-load register sets and operand pointers of the segment being loaded (shared by all segments).
     f32x4 va[DEPTH][NA], vm[DEPTH][NA], vb[DEPTH][NB];
     gfptr pa[NA]; gfptr pm[NA]; gfptr pb[NB]; float lse[NA];
+    float dacc[NA];                                      // DIST: sum (v_o - v_k + 1e-6)^2 over this thread's column quads, per A row
+#pragma unroll
+    for (int i = 0; i < NA; ++i) dacc[i] = 0.f;
     auto setup = [&](auto kind_c, const MainSeg& g) __attribute__((always_inline)) {
         constexpr int KIND = decltype(kind_c)::value;
 #pragma unroll
@@ -148,8 +164,9 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
     typedef std::true_type Tt; typedef std::false_type Ff;
 
     // ---- one segment: its k-steps through the load pipeline ----------------------------------------------------------
-    // On entry tiles 0 .. DEPTH-1 of the segment are in flight in register sets 0 .. DEPTH-1 and `pa/pm/pb/lse` are its pointers.
-    auto run_seg = [&](auto idx_c) __attribute__((always_inline)) {
+    // On entry tiles t0 .. t0+DEPTH-1 of the segment are in flight in register sets 0 .. DEPTH-1 and `pa/pm/pb/lse` are its
+    // pointers.  [t0, t1): the segment's steps that fall into this workgroup's range; pf_next: the next segment follows.
+    auto run_seg = [&](auto idx_c, const int t0, const int t1, const bool pf_next) __attribute__((always_inline)) {
         constexpr int I = decltype(idx_c)::value;
         constexpr int KIND = KS[I], NKIND = KS[I + 1];                      // NKIND < 0: last segment
         constexpr int LKIND = KIND == MK_GATHER_MUL ? LK_MUL : KIND == MK_SOFTMAX ? LK_SOFTMAX : LK_PLAIN;
@@ -160,13 +177,20 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
         float lse_c[NA];
 #pragma unroll
         for (int i = 0; i < NA; ++i) lse_c[i] = lse[i];
-        // transform + LDS store of the tile in register set S; items [h0, h1)
-        auto stash = [&](auto set_c, int buf, int h0, int h1) __attribute__((always_inline)) {
+        // transform + LDS store of the tile in register set S; items [h0, h1).  PATCH (DIST, first tile of the segment after
+        // v_o * v_k): column 0 <- the distance just accumulated
+        auto stash = [&](auto set_c, auto patch_c, int buf, int h0, int h1) __attribute__((always_inline)) {
             constexpr int S = decltype(set_c)::value;
+            constexpr bool PATCH = decltype(patch_c)::value;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 if (i < h0 || i >= h1) continue;
                 f32x4 v = va[S][i];
+                if (DIST && LKIND == LK_MUL) {
+                    const f32x4 df = vm[S][i] - va[S][i] + 1e-6f;            // v_o - v_k + eps (cx.py:300)
+                    dacc[i] += (df[0] * df[0] + df[1] * df[1]) + (df[2] * df[2] + df[3] * df[3]);
+                }
+                if (PATCH) v[0] = quad == 0 ? dacc[i] : v[0];
                 if (LKIND == LK_MUL) v = v * vm[S][i];
                 if (LKIND == LK_SOFTMAX) {
 #pragma unroll
@@ -180,9 +204,20 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
                 *(f32x4*)(lds_b + buf * BN * P + (trow + 32 * i) * P + 4 * quad) = vb[S][i];
             }
         };
-        // prologue: tile 0 -> LDS buffer 0 (DEPTH 2: tile 2 into the freed set)
-        stash(S0{}, 0, 0, NA + NB);
-        issue(S0{}, MULC{}, klen, nst, DEPTH);
+        // prologue: tile t0 -> LDS buffer 0 (DEPTH 2: tile t0+2 into the freed set)
+        if constexpr (DIST && I == 2) {                  // the 8 threads of a row hold its partial sums: reduce, sqrt, keep, store
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                float d2 = dacc[i];
+                d2 += __shfl_xor(d2, 1, 64); d2 += __shfl_xor(d2, 2, 64); d2 += __shfl_xor(d2, 4, 64);
+                dacc[i] = sqrtf(d2);
+                const int r = m0 + trow + 32 * i;
+                if (quad == 0 && tn == 0 && trow + 32 * i < BM && r < M) args.dist_out[(long long)r * args.ld_dist] = dacc[i];
+            }
+            stash(S0{}, Tt{}, 0, 0, NA + NB);
+        } else
+        stash(S0{}, Ff{}, 0, 0, NA + NB);
+        issue(S0{}, MULC{}, klen, nst, t0 + DEPTH);
         __syncthreads();
 
         // step t (parity PAR = t & 1): LDS buffer PAR holds tile t; DEPTH 2: set PAR^1 holds tile t+1, set PAR tile t+2;
@@ -197,7 +232,7 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
 #pragma unroll
             for (int q = 0; q < NMF; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
             __builtin_amdgcn_sched_barrier(0);
-            if (LAST && NKIND >= 0) {
+            if (LAST && NKIND >= 0 && pf_next) {
                 const MainSeg& nx = args.seg[I + 1 < MAIN_MAX_SEG ? I + 1 : I];
                 setup(IntC<NKIND>{}, nx);
                 const int kn = nx.klen, nn = (kn + BK - 1) / BK;
@@ -211,8 +246,8 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
                 auto& afn = (s & 1) ? afA : afB; auto& bfn = (s & 1) ? bfA : bfB;
                 read_frags(PAR, s + 1, afn, bfn);
                 if (!LAST) {
-                    if (s == 0) stash(SS{}, PAR ^ 1, 0, (NA + NB) / 2);
-                    if (s == 1) stash(SS{}, PAR ^ 1, (NA + NB) / 2, NA + NB);
+                    if (s == 0) stash(SS{}, Ff{}, PAR ^ 1, 0, (NA + NB) / 2);
+                    if (s == 1) stash(SS{}, Ff{}, PAR ^ 1, (NA + NB) / 2, NA + NB);
                     if (s == 2) issue(SS{}, MULC{}, klen, nst, t + 1 + DEPTH);
                 }
                 mfma(afc, bfc);
@@ -229,30 +264,59 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
             __syncthreads();
         };
         typedef IntC<0> P0; typedef IntC<1> P1;
-        int t = 0;
-        for (; t + 2 < nst; t += 2) { step(P0{}, Ff{}, t); step(P1{}, Ff{}, t + 1); }            // t + 1 <= nst - 2
-        if (t + 1 < nst) { step(P0{}, Ff{}, t); step(P1{}, Tt{}, t + 1); }
+        int t = t0;                                                                               // (parity = (t - t0) & 1)
+        for (; t + 2 < t1; t += 2) { step(P0{}, Ff{}, t); step(P1{}, Ff{}, t + 1); }              // t + 1 <= t1 - 2
+        if (t + 1 < t1) { step(P0{}, Ff{}, t); step(P1{}, Tt{}, t + 1); }
         else step(P0{}, Tt{}, t);
     };
 
-    setup(IntC<K0>{}, args.seg[0]);
-    {
-        const MainSeg& g = args.seg[0];
-        const int nn = (g.klen + BK - 1) / BK;
-        typedef std::integral_constant<bool, K0 == MK_GATHER_MUL> M0;
-        issue(S0{}, M0{}, g.klen, nn, 0);
-        if (DEPTH == 2) issue(S1{}, M0{}, g.klen, nn, 1);
-    }
-    run_seg(IntC<0>{}); stamp(1);
-    if constexpr (NSEG > 1) { run_seg(IntC<1>{}); stamp(2); }
-    if constexpr (NSEG > 2) { run_seg(IntC<2>{}); stamp(3); }
-    if constexpr (NSEG > 3) { run_seg(IntC<3>{}); stamp(4); }
-    if constexpr (NSEG > 4) { run_seg(IntC<4>{}); stamp(5); }
+    // segment I runs its steps [lo, hi) = [g0, g1) intersected with the segment; the first one that has any loads its own
+    // first tiles, every later one finds them loaded by its predecessor's last step
+    bool started = false;
+    int base = 0;
+    auto seg_pass = [&](auto idx_c) __attribute__((always_inline)) {
+        constexpr int I = decltype(idx_c)::value;
+        const int nst = nsteps[I];
+        const int lo = min(max(g0 - base, 0), nst), hi = min(max(g1 - base, 0), nst);
+        base += nst;
+        if (lo < hi) {
+            if (!started) {
+                const MainSeg& g = args.seg[I];
+                setup(IntC<KS[I]>{}, g);
+                typedef std::integral_constant<bool, KS[I] == MK_GATHER_MUL> MI;
+                issue(S0{}, MI{}, g.klen, nst, lo);
+                if (DEPTH == 2) issue(S1{}, MI{}, g.klen, nst, lo + 1);
+                started = true;
+            }
+            run_seg(idx_c, lo, hi, g1 > base);           // (g1 > base: the range continues into the next segment)
+        }
+        stamp(1 + I);
+    };
+    seg_pass(IntC<0>{});
+    if constexpr (NSEG > 1) seg_pass(IntC<1>{});
+    if constexpr (NSEG > 2) seg_pass(IntC<2>{});
+    if constexpr (NSEG > 3) seg_pass(IntC<3>{});
+    if constexpr (NSEG > 4) seg_pass(IntC<4>{});
     mfma(afB, bfB);                                      // the last sub-step of the last segment
 
     // ---- epilogue: + Sh[r / K] (+ bias), ReLU, Dropout, store ---------------------------------------------------------
     // Every operand is fetched behind one uniform test per kind (a test per element puts each load in its own basic block:
     // 24 serialised round trips); r / K of a lane's 4 consecutive rows comes from ONE division.
+    if (S > 1) {                                         // raw partial sums -> slab[z]; the epilogue runs in k_main_fixup
+        float* const slab = args.slab + (long long)z * M * N;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                const int n = n0 + wn0 + 16 * j + li;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = m0 + wm0 + 16 * i + 4 * lk + q;
+                    if (r < M && n < N) slab[(long long)r * N + n] = acc[i][j][q];
+                }
+            }
+        return;
+    }
     const EpiArgs& e = args.epi;
     const int rdiv = e.rowadd ? e.rowdiv : 1;
 #pragma unroll
@@ -316,18 +380,45 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
     if (stamps && tid == 0) stamps[15] = __builtin_amdgcn_s_memrealtime();
 }
 
+// out[r][n] = epilogue(sum_z slab[z][r][n]): 4 consecutive n per thread (N % 4 != 0: scalar tail), z ascending (deterministic)
+__global__ __launch_bounds__(256) void k_main_fixup(const MainArgs a) {
+    const int M = a.M, N = a.N, S = a.split;
+    const int nq = (N + 3) / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)M * nq) return;
+    const int r = (int)(i / nq), n0 = (int)(i - (long long)r * nq) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const long long mn = (long long)M * N, off = (long long)r * N + n0;
+    for (int z = 0; z < S; ++z)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (n0 + j < N) v[j] += a.slab[z * mn + off + j];
+    const EpiArgs& e = a.epi;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + j;
+        if (n >= N) break;
+        a.out[(long long)r * a.ldo + n] = apply_epilogue(e, v[j], r, n, N);
+    }
+}
+
 // Operand requirements of the kernel (see the header comment): klen >= 4 and a multiple of 4; weight rows readable (zero
 // padded) up to the next multiple of 32 columns.
 static inline bool main_fwd_operand_ok(int klen) { return klen >= 4 && klen % 4 == 0; }
 
-template <class CFG, int... KINDS>
+template <class CFG, bool DIST, int... KINDS>
 static inline int launch_main_fwd_seq(MainArgs& a, hipStream_t s) {
     static bool attr = false;
-    if (!attr) { NCX_HIP_TRY(hipFuncSetAttribute((const void*)k_main_fwd<CFG, KINDS...>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS)); attr = true; }
+    if (!attr) { NCX_HIP_TRY(hipFuncSetAttribute((const void*)k_main_fwd<CFG, DIST, KINDS...>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS)); attr = true; }
     const int tiles_m = (a.M + CFG::BM - 1) / CFG::BM, tiles_n = (a.N + CFG::BN - 1) / CFG::BN;
-    const int grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
-    hipLaunchKernelGGL((k_main_fwd<CFG, KINDS...>), dim3(grid), dim3(MF_T), CFG::LDS, s, a);
+    const int S = a.split > 1 ? a.split : 1;
+    const int grid = ((tiles_m * S + 7) / 8) * 8 * tiles_n;
+    hipLaunchKernelGGL((k_main_fwd<CFG, DIST, KINDS...>), dim3(grid), dim3(MF_T), CFG::LDS, s, a);
     NCX_HIP_TRY(hipGetLastError());
+    if (S > 1) {
+        const long long nthreads = (long long)a.M * ((a.N + 3) / 4);
+        hipLaunchKernelGGL(k_main_fixup, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, s, a);
+        NCX_HIP_TRY(hipGetLastError());
+    }
     return NCX_OK;
 }
 
@@ -337,13 +428,20 @@ static inline int launch_main_fwd(MainArgs& a, hipStream_t s) {
     if (a.nseg < 1 || a.nseg > MAIN_MAX_SEG || a.M < 1 || a.N < 1) return NCX_E_DIMS;
     for (int i = 0; i < a.nseg; ++i) if (!main_fwd_operand_ok(a.seg[i].klen)) return NCX_E_DIMS;
     if (a.epi.rowadd && a.epi.rowdiv < 3) return NCX_E_DIMS;                        // (the epilogue's row -> triplet map assumes K >= 3)
+    if (a.split > 1 && !a.slab) return NCX_E_WORKSPACE;
     auto is = [&](std::initializer_list<int> ks) { if ((int)ks.size() != a.nseg) return false; int i = 0; for (int k : ks) if (a.seg[i++].kind != k) return false; return true; };
     constexpr int G = MK_GATHER, X = MK_GATHER_MUL, P = MK_PLAIN, S = MK_SOFTMAX;
-    if (is({G, X, P, P, S})) return launch_main_fwd_seq<CFG, G, X, P, P, S>(a, s);
-    if (is({P}))             return launch_main_fwd_seq<CFG, P>(a, s);
-    if (is({G, P, P, S}))    return launch_main_fwd_seq<CFG, G, P, P, S>(a, s);
-    if (is({G, X, P, P, P})) return launch_main_fwd_seq<CFG, G, X, P, P, P>(a, s);
-    if (is({G, P, P, P}))    return launch_main_fwd_seq<CFG, G, P, P, P>(a, s);
+    if (a.dist_out) {                        // (in-kernel pairwise distance: whole k range in one workgroup, no slid windows in the v rows)
+        if (a.split > 1 || a.nseg < 3 || a.seg[1].klen % MF_BK) return NCX_E_FLAGS;
+        if (is({G, X, P, P, S})) return launch_main_fwd_seq<CFG, true, G, X, P, P, S>(a, s);
+        if (is({G, X, P, P, P})) return launch_main_fwd_seq<CFG, true, G, X, P, P, P>(a, s);
+        return NCX_E_FLAGS;
+    }
+    if (is({G, X, P, P, S})) return launch_main_fwd_seq<CFG, false, G, X, P, P, S>(a, s);
+    if (is({P}))             return launch_main_fwd_seq<CFG, false, P>(a, s);
+    if (is({G, P, P, S}))    return launch_main_fwd_seq<CFG, false, G, P, P, S>(a, s);
+    if (is({G, X, P, P, P})) return launch_main_fwd_seq<CFG, false, G, X, P, P, P>(a, s);
+    if (is({G, P, P, P}))    return launch_main_fwd_seq<CFG, false, G, P, P, P>(a, s);
     return NCX_E_FLAGS;
 }
 

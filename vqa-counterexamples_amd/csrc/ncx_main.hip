@@ -13,11 +13,20 @@ typedef MainCfg<96, 128, 2, 2, 2, 1> MainCfg2;      // one workgroup per CU with
 // batches (data-parallel shards: 64 triplets per GPU) take the 48-row tile: twice the workgroups.
 int main_forward(MainArgs& a, hipStream_t s) {
     const long long tiles96 = (long long)((a.M + 95) / 96) * ((a.N + 127) / 128);
-    int cfg = tiles96 * 10 >= (long long)num_cus() * 9 ? 2 : 0;
+    int cfg = (a.split <= 1 && tiles96 * 10 >= (long long)num_cus() * 9) ? 2 : 0;
     if (const char* e = hook_env("NCX_MAIN_CFG")) cfg = atoi(e);       // experiment hook (NCX_EXPERIMENT=1)
     if (cfg == 1) return launch_main_fwd<MainCfg1>(a, s);
     if (cfg == 2) return launch_main_fwd<MainCfg2>(a, s);
     return launch_main_fwd<MainCfg0>(a, s);
+}
+
+int main_split(long long M, long long N, long long T) {
+    const long long tiles = ((M + 47) / 48) * ((N + 127) / 128), cus = num_cus();
+    if (tiles >= cus) return 1;
+    long long S = 2 * cus / tiles;                  // all workgroups resident at once (two per CU): one round, no tail
+    if (S > T / 8) S = T / 8;
+    if (const char* e = hook_env("NCX_MAIN_SPLIT")) S = atoll(e);      // experiment hook (NCX_EXPERIMENT=1)
+    return (int)(S < 1 ? 1 : S);
 }
 
 }  // namespace ncx
