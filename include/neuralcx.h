@@ -159,6 +159,8 @@ int ncx_backward_phase(const ncx_dims* d, const ncx_inputs* in, const ncx_params
 
 /* Byte offset (from the 256-byte aligned workspace base) and size of a named workspace region. */
 #define NCX_WS_DGT 1
+#define NCX_WS_H1 2     /* diagnostics / tests: post-dropout activations of linear_1, [B*K, H] (valid after ncx_forward) */
+#define NCX_WS_DPRE1 3  /* diagnostics / tests: gradient of linear_1's pre-activations, [B*K, H] (valid after ncx_backward) */
 int ncx_ws_region(const ncx_dims* d, int32_t which, size_t* offset, size_t* bytes);
 
 /* Replaces torch.optim.Adam(...).step() (counterexamples.py:275-276,339) on a flat fp32 buffer:

@@ -358,9 +358,12 @@ def test_one_train_step_matches_golden_adam():
         M = torch.zeros_like(P); V = torch.zeros_like(P)
         ops.adam_step(P, G, M, V, 1, lr=1e-4)
         ref = g["adam1/" + k].reshape(-1)
-        # Adam normalises by sqrt(v): entries whose gradient is round-off noise (|g| ~ 1e-9) move by +-lr either way
-        big = np.abs(g["grad/" + k].reshape(-1)) > 1e-6 * np.abs(g["grad/" + k]).max()
+        # Adam normalises by sqrt(v): the first step moves every entry by lr * sign(g), so a RELATIVE gradient error eps becomes a
+        # parameter error ~eps * lr.  The gradients agree to 1e-4 of the tensor's max (checked above): entries above 1e-2 of the
+        # max are within 1e-2 relative, i.e. 1e-6 here (lr = 1e-4); smaller entries may move by up to +-lr either way
+        big = np.abs(g["grad/" + k].reshape(-1)) > 1e-2 * np.abs(g["grad/" + k]).max()
         assert np.abs(P.cpu().numpy() - ref)[big].max() <= 2e-6, k
+        assert np.abs(P.cpu().numpy() - ref).max() <= 2.01e-4, k
 
 
 def test_phased_backward_is_bit_identical():

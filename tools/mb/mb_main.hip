@@ -133,6 +133,12 @@ int main(int argc, char** argv) {
         float* dist_buf; CHECK(hipMalloc(&dist_buf, (size_t)M * 28 * 4));
         add("real + in-kernel dist 96x128 d2 o1", [&] { MainArgs a = p.full; a.dist_out = dist_buf; a.ld_dist = 28; launch_main_fwd<C_96_128_d2_o1>(a, 0); });
         add("real + in-kernel dist 48x128 d2", [&] { MainArgs a = p.full; a.dist_out = dist_buf; a.ld_dist = 28; launch_main_fwd<CB>(a, 0); });
+        typedef MainCfg<48, 64, 1, 4, 2, 2> CF;
+        Problem pf = p; pf.full.seg[0].kind = MK_VFOLD; pf.full.seg[0].idx2 = idx_o; pf.full.seg[0].b2 = p.full.seg[1].b;
+        pf.full.seg[1] = p.full.seg[2]; pf.full.seg[2] = p.full.seg[3]; pf.full.seg[3] = p.full.seg[4]; pf.full.nseg = 4;
+        add("fold 48x64", [&] { MainArgs a = pf.full; launch_main_fwd<CF>(a, 0); });
+        add("fold 48x64 + dist", [&] { MainArgs a = pf.full; a.dist_out = dist_buf; a.ld_dist = 28; launch_main_fwd<CF>(a, 0); });
+        add("real 48x64 (no fold)", [&] { MainArgs a = p.full; launch_main_fwd<CF>(a, 0); });
         hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
         for (int round = 0; round < 7; ++round)
             for (auto& v : vs) {

@@ -946,8 +946,13 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
     }
     // the pairwise distance rides in the fused forward kernel when that kernel sees whole v rows (no k-split, no slid windows)
     long long main_T = ks(d.dv) * ((d.flags & NCX_F_V_MULT) ? 2 : 1) + ks(w.ldm) + ks(d.dz) + (aemb ? ks(d.A) : ks(d.da));
+    // K = 24, whole 32-column tiles, no k-split: the two v segments as one pass with the per-triplet fold (ncx_main.h, MK_VFOLD)
+    const bool vfold = main_fwd_dims_ok(d) && (d.flags & NCX_F_V_MULT) && d.K == 24 && d.dv % 32 == 0 && d.dv >= 64 &&
+                       main_split(M, H, main_T) == 1 && !hook_env("NCX_NO_VFOLD");
+    // Measured at configs[1]: inside the plain chain the distance costs the kernel 12 us and saves k_prep 30; inside the fold's
+    // 48 x 64 tiles (a quarter of the MFMA work per vector instruction) it costs 31 us: there k_prep keeps computing it.
     const bool dist_in_main = main_fwd_dims_ok(d) && (d.flags & NCX_F_V_DIST) && (d.flags & NCX_F_V_MULT) && d.dv % 32 == 0 &&
-                              main_split(M, H, main_T) == 1 && !(hook_env("NCX_NO_DIST_IN_MAIN"));
+                              main_split(M, H, main_T) == 1 && !vfold && !(hook_env("NCX_NO_DIST_IN_MAIN"));
     ncx_dims dprep = d;
     if (dist_in_main) dprep.flags |= NCX_F_PRIV_DIST_IN_MAIN;
     const unsigned prep_grid = (unsigned)(cdiv(M, 4) + (long long)H * pk.n);
@@ -1003,8 +1008,13 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
         auto seg = [&](int kind, const float* x, long long lda, int klen, const int* i1, const int* i2, const float* lse, int slot, const float* wgt, long long ldb) {
             MainSeg& g = a.seg[n++]; g.kind = kind; g.a = x; g.lda = lda; g.idx = i1; g.idx2 = i2; g.lse = lse; g.klen = klen;
             if (slot >= 0 && wp.width[slot]) { g.b = wp.ptr[slot]; g.ldb = wp.width[slot]; } else { g.b = wgt; g.ldb = ldb; } };
-        seg(MK_GATHER, in->feats, d.dv, d.dv, idx_k, nullptr, nullptr, 0, p->w1 + o.v_other, din);
-        if (d.flags & NCX_F_V_MULT) seg(MK_GATHER_MUL, in->feats, d.dv, d.dv, idx_k, idx_o, nullptr, 1, p->w1 + o.v_mult, din);
+        if (vfold) {
+            seg(MK_VFOLD, in->feats, d.dv, d.dv, idx_k, idx_o, nullptr, -1, p->w1 + o.v_other, din);
+            a.seg[0].b2 = p->w1 + o.v_mult;
+        } else {
+            seg(MK_GATHER, in->feats, d.dv, d.dv, idx_k, nullptr, nullptr, 0, p->w1 + o.v_other, din);
+            if (d.flags & NCX_F_V_MULT) seg(MK_GATHER_MUL, in->feats, d.dv, d.dv, idx_k, idx_o, nullptr, 1, p->w1 + o.v_mult, din);
+        }
         seg(MK_PLAIN, misc, w.ldm, w.ldm, nullptr, nullptr, nullptr, 2, p->w1 + o.v_dist, din);       // (ldm - K - 1 zero columns on both sides)
         seg(MK_PLAIN, in->z_knns, d.dz, d.dz, nullptr, nullptr, nullptr, 3, p->w1 + o.z_other, din);
         if (aemb) seg(MK_SOFTMAX, in->a_knns, d.A, d.A, nullptr, nullptr, mx, -1, gt, w.ldgt);
@@ -1291,8 +1301,13 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
 int ncx_ws_region(const ncx_dims* dp, int32_t which, size_t* offset, size_t* bytes) {
     if (check_dims(dp) != NCX_OK) return NCX_E_DIMS;
     if (!offset || !bytes) return NCX_E_NULL;
-    if (which != NCX_WS_DGT) return NCX_E_FLAGS;
+    if (which != NCX_WS_DGT && which != NCX_WS_H1 && which != NCX_WS_DPRE1) return NCX_E_FLAGS;
     const WsLayout w = ws_layout(*dp);
+    if (which == NCX_WS_H1 || which == NCX_WS_DPRE1) {
+        *offset = which == NCX_WS_H1 ? w.h[0] : w.dpre[(dp->L - 1) & 1];
+        *bytes = (size_t)dp->B * dp->K * dp->H * 4;
+        return NCX_OK;
+    }
     *offset = w.dgt;
     *bytes = (dp->flags & NCX_F_A_EMB) ? (size_t)2 * dp->H * dp->A * 4 : 0;
     return NCX_OK;

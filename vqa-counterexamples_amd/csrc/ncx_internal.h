@@ -70,7 +70,11 @@ constexpr int NCX_COLSUM_CHUNKS = 256;
 
 // ncx_main.hip: the fused forward kernel of the Linear layers (segments of never-materialised operands chained into one
 // accumulator; Sh / bias / ReLU / Dropout in the epilogue)
-enum MainKind : int { MK_PLAIN = 0, MK_GATHER = 1, MK_GATHER_MUL = 2, MK_SOFTMAX = 3 };
+enum MainKind : int { MK_PLAIN = 0, MK_GATHER = 1, MK_GATHER_MUL = 2, MK_SOFTMAX = 3,
+                      // the v_other and v_orig * v_other segments as ONE pass over the v_k rows against per-triplet effective
+                      // weights W_k + diag(v_o[b]) W_m (the forward twin of the weight gradient's per-triplet fold); first
+                      // segment only, K == 24, 48 x 64 tiles
+                      MK_VFOLD = 4 };
 constexpr int MAIN_MAX_SEG = 5;
 struct MainSeg {
     const float* a;      // operand rows: x(r, c) = a[row(r) * lda + c], row(r) = r or idx[r]
@@ -78,6 +82,7 @@ struct MainSeg {
     const int*   idx2;   // MK_GATHER_MUL: x(r, c) = a[idx[r]][c] * a[idx2[r]][c]        (v_other * v_orig, cx.py:296)
     const float* lse;    // MK_SOFTMAX: x(r, c) = exp2(a[r][c] * log2(e) - lse[r])        (softmax(a_knns), cx.py:281)
     const float* b;      // weight slice: w(n, c) = b[n * ldb + c]
+    const float* b2;     // MK_VFOLD: the second weight slice (linear_1.weight[:, v_mult]), same ldb
     long long lda, ldb;
     int kind, klen;      // klen: reduction extent (columns of the segment), >= 4
 };

@@ -45,6 +45,7 @@ struct MainCfg {
     static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, DEPTH = DEPTH_, OCC = OCC_;
     static constexpr int BM_LDS = (BM + 31) / 32 * 32;            // A rows held in LDS (a multiple of the 32-row loader pass)
     static constexpr int LDS = 2 * (BM_LDS + BN) * MF_P * 4;
+    static constexpr int LDS_FOLD = 2 * (80 + 2 * 64) * MF_P * 4;    // MK_VFOLD phase: A 80 rows, two effective weight tiles
 };
 
 typedef const __attribute__((address_space(1))) float* gfptr;      // global address space: global_load, never flat_load
@@ -53,7 +54,10 @@ typedef const __attribute__((address_space(1))) f32x4u* gf4ptr;
 
 template <class CFG, bool DIST, int K0, int K1 = -1, int K2 = -1, int K3 = -1, int K4 = -1>
 __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args) {
-    static_assert(!DIST || (K1 == MK_GATHER_MUL && K2 == MK_PLAIN), "DIST: v_o * v_k segment followed by the dist | rank segment");
+    constexpr bool VFOLD = K0 == MK_VFOLD;
+    constexpr int DIST_SEG = VFOLD ? 1 : 2;              // the (dist | rank) segment: right after the one that streams v_o and v_k
+    static_assert(!DIST || (VFOLD ? K1 == MK_PLAIN : (K1 == MK_GATHER_MUL && K2 == MK_PLAIN)), "DIST: v_o, v_k segment followed by the dist | rank segment");
+    static_assert(!VFOLD || (CFG::BM == 48 && CFG::BN == 64 && CFG::WGM == 1 && CFG::WGN == 4 && CFG::DEPTH == 2), "fold: 48 x 64 tiles");
     constexpr int KS[6] = {K0, K1, K2, K3, K4, -1};
     constexpr int NSEG = K1 < 0 ? 1 : K2 < 0 ? 2 : K3 < 0 ? 3 : K4 < 0 ? 4 : 5;
     constexpr int BM = CFG::BM, BN = CFG::BN, BK = MF_BK, P = MF_P, DEPTH = CFG::DEPTH, BML = CFG::BM_LDS;
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
             }
         };
         // prologue: tile t0 -> LDS buffer 0 (DEPTH 2: tile t0+2 into the freed set)
-        if constexpr (DIST && I == 2) {                  // the 8 threads of a row hold its partial sums: reduce, sqrt, keep, store
+        if constexpr (DIST && I == DIST_SEG) {                  // the 8 threads of a row hold its partial sums: reduce, sqrt, keep, store
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 float d2 = dacc[i];
@@ -270,6 +274,159 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
         else step(P0{}, Tt{}, t);
     };
 
+    // ---- MK_VFOLD: v_k . (W_k + diag(v_o[b]) W_m)^T for the two triplets of the tile ------------------------------------------
+    // (v_o * v_k) . W_m^T = v_k . (diag(v_o) W_m)^T and the 24 candidate rows of a triplet share v_o, so the two 2048-deep
+    // segments become ONE pass over the v_k rows against a per-triplet effective weight tile built on the vector ALU at LDS-store
+    // time (2 x 64 x 32 FMAs per k-step).  MFMA row blocks must be triplet-pure: each triplet's 24 rows sit in 32 LDS rows
+    // (8 zero rows), i.e. 4 block rows instead of the 2 x 3 of the two plain segments: 2/3 of their MFMA work.  Waves 2 x 2:
+    // wave (wr, wc) = triplet wr x column half wc.  The accumulators of this phase live in the padded row layout; they pass
+    // through LDS once into the compact 48-row layout of the segments that follow.
+    auto run_vfold = [&](const MainSeg& sg, const bool pf_next) __attribute__((always_inline)) {
+        constexpr int AR = 80;                              // A rows in LDS: 2 x 32 (24 + 8 zero rows) + 16 dump rows for the loader's idle items
+        float* const fa = mf_smem;                          // [2][AR][P]
+        float* const fb = mf_smem + 2 * AR * P;             // [2][2 triplets][64][P]
+        const int klen = sg.klen, nst = klen / BK;
+        const int wr = wave >> 1, wc = wave & 1;
+        gfptr pk[2], pwk[2], pwm[2], po[2];
+        int lrow[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rho = trow + 32 * i;                                        // tile row 0 .. 63 (>= 48: idle)
+            const int r = min(m0 + min(rho, BM - 1), M - 1);
+            pk[i] = (gfptr)sg.a + (long long)((giptr)sg.idx)[r] * sg.lda;
+            lrow[i] = rho < 24 ? rho : rho < 48 ? rho + 8 : 64 + (rho - 48);
+            const int n = min(n0 + trow + 32 * i, N - 1);
+            pwk[i] = (gfptr)sg.b + (long long)n * sg.ldb;
+            pwm[i] = (gfptr)sg.b2 + (long long)n * sg.ldb;
+            po[i] = (gfptr)sg.a + (long long)((giptr)sg.idx2)[min(m0 + 24 * i, M - 1)] * sg.lda;      // v_o of triplet i
+        }
+        const int t_of0 = trow < 24 ? 0 : 1;                                       // triplet of this thread's first A item (the second: 1)
+        f32x4 vk[2][2], vo[2][2], vwk[2][2], vwm[2][2];
+        auto vissue = [&](auto set_c, int t) __attribute__((always_inline)) {
+            constexpr int S = decltype(set_c)::value;
+            const int c = min(t, nst - 1) * BK + 4 * quad;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { vk[S][i] = *(gf4ptr)(pk[i] + c); vo[S][i] = *(gf4ptr)(po[i] + c); vwk[S][i] = *(gf4ptr)(pwk[i] + c); vwm[S][i] = *(gf4ptr)(pwm[i] + c); }
+        };
+        // part 0: the v_k rows + triplet 0's effective weights; part 1: triplet 1's
+        auto vstash = [&](auto set_c, int buf, int part) __attribute__((always_inline)) {
+            constexpr int S = decltype(set_c)::value;
+            if (part == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    if (DIST) {
+                        const f32x4 ov = i == 0 ? (t_of0 == 0 ? vo[S][0] : vo[S][1]) : vo[S][1];
+                        const f32x4 df = ov - vk[S][i] + 1e-6f;                    // v_o - v_k + eps (cx.py:300)
+                        dacc[i] += (df[0] * df[0] + df[1] * df[1]) + (df[2] * df[2] + df[3] * df[3]);
+                    }
+                    *(f32x4*)(fa + buf * AR * P + lrow[i] * P + 4 * quad) = vk[S][i];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = __builtin_fmaf(vo[S][part][e], vwm[S][j][e], vwk[S][j][e]);
+                *(f32x4*)(fb + ((buf * 2 + part) * 64 + trow + 32 * j) * P + 4 * quad) = w;
+            }
+        };
+        // the zero rows of both A buffers (rows 24..31 and 56..63): 2 x 16 rows x 8 quads = 256 quads
+        {
+            const int b = tid >> 7, rr = (tid >> 3) & 15, zr = rr < 8 ? 24 + rr : 48 + rr;
+            *(f32x4*)(fa + b * AR * P + zr * P + 4 * quad) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        f32x4 acc4[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x2 a0[2], b0[2], a1[2], b1[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { a1[i] = f32x2{0.f, 0.f}; b1[i] = f32x2{0.f, 0.f}; }
+        auto vread = [&](int buf, int s, f32x2 (&af)[2], f32x2 (&bf)[2]) __attribute__((always_inline)) {
+            const float* a = fa + buf * AR * P + (32 * wr + li) * P + 8 * s + 2 * lk;
+            const float* b = fb + ((buf * 2 + wr) * 64 + 32 * wc + li) * P + 8 * s + 2 * lk;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { af[i] = *(const f32x2*)(a + i * 16 * P); bf[i] = *(const f32x2*)(b + i * 16 * P); }
+        };
+        auto vmfma = [&](const f32x2 (&af)[2], const f32x2 (&bf)[2]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc4[i][j], 0, 0, 0);
+        };
+        typedef IntC<0> V0; typedef IntC<1> V1;
+        vissue(V0{}, 0);
+        vissue(V1{}, 1);
+        vstash(V0{}, 0, 0); vstash(V0{}, 0, 1);
+        vissue(V0{}, 2);
+        __syncthreads();
+        auto vstep = [&](auto par_c, auto last_c, int t) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_c)::value;
+            constexpr bool LAST = decltype(last_c)::value;
+            typedef IntC<PAR ^ 1> SS;
+            vread(PAR, 0, a0, b0);
+            vmfma(a1, b1);                                               // (t-1, last sub-step)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+            if (LAST && pf_next) {                                       // the next (plain) segment's first tiles
+                const MainSeg& nx = args.seg[1];
+                setup(IntC<K1 < 0 ? 0 : K1>{}, nx);
+                const int kn = nx.klen, nn = (kn + BK - 1) / BK;
+                issue(S0{}, Ff{}, kn, nn, 0);
+                issue(S1{}, Ff{}, kn, nn, 1);
+            }
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                auto& afc = (s & 1) ? a1 : a0; auto& bfc = (s & 1) ? b1 : b0;
+                auto& afn = (s & 1) ? a0 : a1; auto& bfn = (s & 1) ? b0 : b1;
+                vread(PAR, s + 1, afn, bfn);
+                if (!LAST) {
+                    if (s == 0) vstash(SS{}, PAR ^ 1, 0);
+                    if (s == 1) vstash(SS{}, PAR ^ 1, 1);
+                    if (s == 2) vissue(SS{}, t + 3);
+                }
+                vmfma(afc, bfc);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        };
+        int t = 0;
+        for (; t + 2 < nst; t += 2) { vstep(V0{}, Ff{}, t); vstep(V1{}, Ff{}, t + 1); }
+        if (t + 1 < nst) { vstep(V0{}, Ff{}, t); vstep(V1{}, Tt{}, t + 1); }
+        else vstep(V0{}, Tt{}, t);
+        vmfma(a1, b1);                                                   // the last sub-step
+        // padded (wave = triplet x column half) -> compact (wave = 16 columns, all 48 rows) accumulator layout, through LDS
+        constexpr int CP = 68;
+        float* const fc = mf_smem;                                       // [64 padded rows][CP]   (every fragment read is complete: last barrier)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fc[(32 * wr + 16 * i + 4 * lk + q) * CP + 32 * wc + 16 * j + li] = acc4[i][j][q];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rho = wm0 + 16 * i + 4 * lk + q;                   // compact tile row
+                acc[i][0][q] = fc[(rho < 24 ? rho : rho + 8) * CP + wn0 + li];
+            }
+        __syncthreads();
+    };
+
     // segment I runs its steps [lo, hi) = [g0, g1) intersected with the segment; the first one that has any loads its own
     // first tiles, every later one finds them loaded by its predecessor's last step
     bool started = false;
@@ -292,7 +449,13 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
         }
         stamp(1 + I);
     };
-    seg_pass(IntC<0>{});
+    if constexpr (VFOLD) {
+        run_vfold(args.seg[0], NSEG > 1);
+        base = nsteps[0]; started = true;
+        stamp(1);
+    } else {
+        seg_pass(IntC<0>{});
+    }
     if constexpr (NSEG > 1) seg_pass(IntC<1>{});
     if constexpr (NSEG > 2) seg_pass(IntC<2>{});
     if constexpr (NSEG > 3) seg_pass(IntC<3>{});
@@ -405,14 +568,17 @@ __global__ __launch_bounds__(256) void k_main_fixup(const MainArgs a) {
 // padded) up to the next multiple of 32 columns.
 static inline bool main_fwd_operand_ok(int klen) { return klen >= 4 && klen % 4 == 0; }
 
+template <int K0, int... REST> struct FirstKind { static constexpr int value = K0; };
+
 template <class CFG, bool DIST, int... KINDS>
 static inline int launch_main_fwd_seq(MainArgs& a, hipStream_t s) {
+    constexpr int lds = FirstKind<KINDS...>::value == MK_VFOLD ? (CFG::LDS_FOLD > CFG::LDS ? CFG::LDS_FOLD : CFG::LDS) : CFG::LDS;
     static bool attr = false;
-    if (!attr) { NCX_HIP_TRY(hipFuncSetAttribute((const void*)k_main_fwd<CFG, DIST, KINDS...>, hipFuncAttributeMaxDynamicSharedMemorySize, CFG::LDS)); attr = true; }
+    if (!attr) { NCX_HIP_TRY(hipFuncSetAttribute((const void*)k_main_fwd<CFG, DIST, KINDS...>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = true; }
     const int tiles_m = (a.M + CFG::BM - 1) / CFG::BM, tiles_n = (a.N + CFG::BN - 1) / CFG::BN;
     const int S = a.split > 1 ? a.split : 1;
     const int grid = ((tiles_m * S + 7) / 8) * 8 * tiles_n;
-    hipLaunchKernelGGL((k_main_fwd<CFG, DIST, KINDS...>), dim3(grid), dim3(MF_T), CFG::LDS, s, a);
+    hipLaunchKernelGGL((k_main_fwd<CFG, DIST, KINDS...>), dim3(grid), dim3(MF_T), lds, s, a);
     NCX_HIP_TRY(hipGetLastError());
     if (S > 1) {
         const long long nthreads = (long long)a.M * ((a.N + 3) / 4);
@@ -431,6 +597,20 @@ static inline int launch_main_fwd(MainArgs& a, hipStream_t s) {
     if (a.split > 1 && !a.slab) return NCX_E_WORKSPACE;
     auto is = [&](std::initializer_list<int> ks) { if ((int)ks.size() != a.nseg) return false; int i = 0; for (int k : ks) if (a.seg[i++].kind != k) return false; return true; };
     constexpr int G = MK_GATHER, X = MK_GATHER_MUL, P = MK_PLAIN, S = MK_SOFTMAX;
+    constexpr int V = MK_VFOLD;
+    if (a.seg[0].kind == V) {                // the per-triplet fold of the two v segments: its own tile shape
+        if constexpr (CFG::BM == 48 && CFG::BN == 64 && CFG::WGM == 1 && CFG::DEPTH == 2) {
+            if (a.split > 1 || a.seg[0].klen % MF_BK || a.seg[0].klen < 2 * MF_BK || !a.epi.rowadd || a.epi.rowdiv != 24) return NCX_E_FLAGS;
+            if (a.dist_out) {
+                if (is({V, P, P, S})) return launch_main_fwd_seq<CFG, true, V, P, P, S>(a, s);
+                if (is({V, P, P, P})) return launch_main_fwd_seq<CFG, true, V, P, P, P>(a, s);
+            } else {
+                if (is({V, P, P, S})) return launch_main_fwd_seq<CFG, false, V, P, P, S>(a, s);
+                if (is({V, P, P, P})) return launch_main_fwd_seq<CFG, false, V, P, P, P>(a, s);
+            }
+        }
+        return NCX_E_FLAGS;
+    }
     if (a.dist_out) {                        // (in-kernel pairwise distance: whole k range in one workgroup, no slid windows in the v rows)
         if (a.split > 1 || a.nseg < 3 || a.seg[1].klen % MF_BK) return NCX_E_FLAGS;
         if (is({G, X, P, P, S})) return launch_main_fwd_seq<CFG, true, G, X, P, P, S>(a, s);

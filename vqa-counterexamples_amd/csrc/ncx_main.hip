@@ -6,12 +6,14 @@ namespace ncx {
 typedef MainCfg<48, 128, 1, 4, 2, 2> MainCfg0;      // two workgroups per CU, 48 x 128 tiles (2 triplets at K = 24), loads two k-steps ahead
 typedef MainCfg<96, 64, 2, 2, 1, 2> MainCfg1;
 typedef MainCfg<96, 128, 2, 2, 2, 1> MainCfg2;      // one workgroup per CU with the whole register file
+typedef MainCfg<48, 64, 1, 4, 2, 2> MainCfgFold;    // MK_VFOLD sequences: 48 x 64 tiles (two triplets), two workgroups per CU
 
 // Measured inside the training step at configs[1] (B = 512: 256 tiles of 96 x 128): 338 us with one 96 x 128 workgroup per CU,
 // 346 / 348 us with two 48 x 128 / 96 x 64 workgroups per CU (on back-to-back launches of the kernel alone the order is the
 // other way round: the step leaves the caches in another state).  The big tile needs enough tiles to fill the chip; smaller
 // batches (data-parallel shards: 64 triplets per GPU) take the 48-row tile: twice the workgroups.
 int main_forward(MainArgs& a, hipStream_t s) {
+    if (a.nseg > 0 && a.seg[0].kind == MK_VFOLD) return launch_main_fwd<MainCfgFold>(a, s);
     const long long tiles96 = (long long)((a.M + 95) / 96) * ((a.N + 127) / 128);
     int cfg = (a.split <= 1 && tiles96 * 10 >= (long long)num_cus() * 9) ? 2 : 0;
     if (const char* e = hook_env("NCX_MAIN_CFG")) cfg = atoi(e);       // experiment hook (NCX_EXPERIMENT=1)
