@@ -32,7 +32,7 @@ def tn_split(d):
             if "seg_gemm_kernel" in r["Kernel_Name"] and "false, false" in r["Kernel_Name"] and r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
                 vals[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return vals
-for name, pat in (("MAIN", ("seg_gemm_kernel<96, 128, true, true",)), ("k_prep", ("k_prep",)), ("k_adam", ("k_adam",))):
+for name, pat in (("MAIN", ("k_main_fwd",)), ("k_prep", ("k_prep",)), ("k_adam", ("k_adam",))):
     fk, wk = pick(fetch, pat), pick(write, pat)
     if fk is not None:
         out[name] = {"fetch_kb": round(fk, 1), "write_kb": round(wk or 0, 1), "bytes_per_launch": int(fk * 1024 * 2 + (wk or 0) * 1024)}
