@@ -58,7 +58,7 @@ extern "C" {
 
 typedef struct ncx_dims {
     int32_t B;        /* triplets in this (local) batch                                             */
-    int32_t K;        /* candidates per triplet, knn_size (24 in the reference; <= 64 supported)    */
+    int32_t K;        /* candidates per triplet, knn_size (24 in the reference; 3..64 supported)     */
     int32_t dv;       /* dim_v  image feature width (2048)                                          */
     int32_t dq;       /* dim_q  question embedding width (2400)                                     */
     int32_t dz;       /* dim_mm multimodal fusion width (360)                                       */

@@ -1492,6 +1492,16 @@ int ncx_plan_query(const ncx_dims* d, int32_t gemm_id, int32_t* out6) {
     list_uses(*d, u);
     out6[0] = u[gemm_id].form; out6[1] = (int32_t)u[gemm_id].M; out6[2] = (int32_t)u[gemm_id].N;
     out6[3] = (int32_t)u[gemm_id].ksteps; out6[4] = u[gemm_id].plan.cfg; out6[5] = u[gemm_id].plan.split;
+    // linear_1 / hidden-layer forward: the fused kernel of ncx_main.h (tile codes 5: 48x128, 6: 48x64 with the per-triplet fold)
+    const bool fast = (gemm_id == U_MAIN && main_fwd_dims_ok(*d)) || (gemm_id == U_FWD_L && hidden_fwd_dims_ok(*d) && !(d->flags & NCX_F_BF16));
+    if (fast) {
+        const long long M = (long long)d->B * d->K, T = u[gemm_id].ksteps;
+        const int sp = main_split(M, d->H, T);
+        const bool vfold = gemm_id == U_MAIN && (d->flags & NCX_F_V_MULT) && d->K == 24 && d->dv % 32 == 0 && d->dv >= 64 && sp == 1;
+        const long long tiles96 = ((M + 95) / 96) * ((d->H + 127) / 128);
+        out6[4] = vfold ? 6 : (sp == 1 && tiles96 * 10 >= (long long)num_cus() * 9) ? CFG_96x128 : 5;
+        out6[5] = sp;
+    }
     return NCX_OK;
 }
 
