@@ -150,6 +150,32 @@ int main(int argc, char** argv) {
         for (auto& v : vs) { std::sort(v.ms.begin(), v.ms.end()); printf("   %-30s %7.1f  %7.1f\n", v.name, v.ms[v.ms.size() / 2] * 1e3, v.ms[0] * 1e3); }
         CHECK(hipFree(dA)); CHECK(hipFree(dB));
     }
+    {   // a SHORT chain (the dE shape: M 2000, N 2400, two plain segments of 256): where does a 16-step workgroup spend its time?
+        const int Ms = 2000, Ns = 2400, Ks = 256;
+        float* sA0 = dev_rand((size_t)Ms * Ks, 1.f, 31); float* sA1 = dev_rand((size_t)Ms * Ks, 1.f, 32);
+        float* sB0 = dev_rand((size_t)Ns * Ks, 0.05f, 33); float* sB1 = dev_rand((size_t)Ns * Ks, 0.05f, 34);
+        float* sout; CHECK(hipMalloc(&sout, (size_t)Ms * Ns * 4));
+        MainArgs b{}; b.M = Ms; b.N = Ns; b.nseg = 2; b.out = sout; b.ldo = Ns;
+        b.seg[0].kind = MK_PLAIN; b.seg[0].a = sA0; b.seg[0].lda = Ks; b.seg[0].klen = Ks; b.seg[0].b = sB0; b.seg[0].ldb = Ks;
+        b.seg[1].kind = MK_PLAIN; b.seg[1].a = sA1; b.seg[1].lda = Ks; b.seg[1].klen = Ks; b.seg[1].b = sB1; b.seg[1].ldb = Ks;
+        auto tm = [&](const char* nm, auto cfg_c) {
+            typedef decltype(cfg_c) C;
+            hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+            for (int i = 0; i < 3; ++i) { MainArgs c = b; launch_main_fwd<C>(c, 0); }
+            CHECK(hipEventRecord(e0, 0)); for (int i = 0; i < 10; ++i) { MainArgs c = b; launch_main_fwd<C>(c, 0); } CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            const int tiles_m = (Ms + C::BM - 1) / C::BM, tiles_n = (Ns + C::BN - 1) / C::BN, grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
+            unsigned long long* st; CHECK(hipMalloc(&st, (size_t)grid * 16 * 8)); CHECK(hipMemset(st, 0, (size_t)grid * 16 * 8));
+            MainArgs c = b; c.stamps = st; launch_main_fwd<C>(c, 0); CHECK(hipDeviceSynchronize());
+            std::vector<unsigned long long> h((size_t)grid * 16); CHECK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
+            double s0 = 0, s1 = 0, s2 = 0, dur = 0; int cnt = 0;
+            for (int g = 0; g < grid; ++g) { const unsigned long long* w = &h[g * 16]; if (!w[15]) continue; s0 += w[1] - w[0]; s1 += w[2] - w[1]; s2 += w[8] - w[2]; dur += (w[15] - w[14]) / 100.0; ++cnt; }
+            printf("   short chain %-14s %6.1f us/launch  %d workgroups: seg0 %6.0f  seg1 %6.0f  epilogue %6.0f cycles, mean workgroup %.1f us\n", nm, ms * 100, cnt, s0 / cnt, s1 / cnt, s2 / cnt, dur / cnt);
+            CHECK(hipFree(st));
+        };
+        printf("-- short chain (dE shape)\n");
+        tm("48x128 d2 o2", C_48_128_d2_o2{}); tm("96x128 d2 o1", C_96_128_d2_o1{}); tm("96x64 d1 o2", C_96_64_d1_o2{}); tm("64x64 d2 o3", C_64_64_d2_o3{});
+    }
     {   // in-kernel stamps of one launch of the library's configuration: where does a workgroup's time go?
         typedef C_48_128_d2_o2 C;
         const int tiles_m = (M + C::BM - 1) / C::BM, tiles_n = (H + C::BN - 1) / C::BN, grid = ((tiles_m + 7) / 8) * 8 * tiles_n;

@@ -486,6 +486,63 @@ __global__ __launch_bounds__(256) void k_scatter_dsh_by_answer(const float* __re
     }
 }
 
+// fp32 path: the answer-embedding gradient runs on the fused forward kernel (ncx_main.h, NT form, 64 x 64 tiles at three
+// workgroups per CU: 50 us against 80 us for the TN form of the generic engine -- tools/mb/mb_main.hip, "short chain"):
+//   dE[a][j] = sum_n dGt^T[a][n] W1ak^T[j][n] + sum_n dGgt^T[a][n] W1agt^T[j][n]
+// whose operands are rows with the reduction index contiguous.  ONE launch prepares them (roles by block range):
+//   [0, B)            dGgt^T[id][n] = sum over {b : aid[b] == id} of dSh[b][n]   (owner-computes scatter as above, rows contiguous now;
+//                     dGgt^T was cleared by k_bwd_prelude)
+//   [B, B + T)        32 x 32 transposes through LDS: dGt [H][A] -> dGt^T [A][Hp4];  W1[:, a_other], W1[:, a_gt] -> [da][Hp32]
+//                     (columns beyond H zero: the kernel's weight-side padding)
+struct EmbPrepArgs {
+    const float* dsh; const int* aid; float* dggtT;        // scatter
+    const float* src[3]; float* dst[3]; long long lds_[3]; int cols[3], ldd[3], dcols[3], tile0[4];   // transposes: src [H][cols] -> dst [cols][ldd], dst cols < dcols written
+    int B, H, A, Hp4;
+};
+__global__ __launch_bounds__(256) void k_emb_prep(const EmbPrepArgs a) {
+    __shared__ unsigned bits[NCX_SCATTER_MAX_B / 32 > 32 * 33 ? NCX_SCATTER_MAX_B / 32 : 32 * 33];     // scatter: id bitmap; transposes: a [32][33] tile
+    if ((int)blockIdx.x < a.B) {
+        const int b = blockIdx.x, B = a.B;
+        const int id = a.aid[b];
+        int earlier = 0;
+        for (int j = threadIdx.x; j < b; j += 256) earlier |= a.aid[j] == id;
+        if (__syncthreads_or(earlier)) return;                       // not the owner (uniform per block)
+        const int nw = (B + 31) / 32;
+        for (int w = threadIdx.x; w < nw; w += 256) bits[w] = 0u;
+        __syncthreads();
+        for (int j = b + threadIdx.x; j < B; j += 256)
+            if (a.aid[j] == id) atomicOr(&bits[j >> 5], 1u << (j & 31));
+        __syncthreads();
+        for (int n = threadIdx.x; n < a.H; n += 256) {
+            float s = 0.f;
+            for (int w = b >> 5; w < nw; ++w) {
+                unsigned m = bits[w];
+                while (m) { const int j = (w << 5) + __ffs(m) - 1; m &= m - 1; s += a.dsh[(long long)j * a.H + n]; }
+            }
+            a.dggtT[(long long)id * a.Hp4 + n] = s;
+        }
+        return;
+    }
+    float* tile = (float*)bits;                                        // [32][33]
+    int t = blockIdx.x - a.B, e = 0;
+    while (e < 2 && t >= a.tile0[e + 1]) ++e;
+    t -= a.tile0[e];
+    const int tiles_h = (a.dcols[e] + 31) / 32;                        // tiles along the source-row (h) direction
+    const int th = t % tiles_h, tc = t / tiles_h;
+    const int x = threadIdx.x & 31, y = threadIdx.x >> 5;              // 32 x 8 threads
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int h = th * 32 + y + 8 * i, c = tc * 32 + x;
+        tile[(y + 8 * i) * 33 + x] = (h < a.H && c < a.cols[e]) ? a.src[e][(long long)h * a.lds_[e] + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tc * 32 + y + 8 * i, h = th * 32 + x;
+        if (c < a.cols[e] && h < a.dcols[e]) a.dst[e][(long long)c * a.ldd[e] + h] = tile[x * 33 + y + 8 * i];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_zero_cols(float* __restrict__ p, int rows, long long ld, int cols) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)rows * cols) return;
@@ -726,6 +783,8 @@ WsLayout ws_layout(const ncx_dims& d) {
     w.dsh = take((size_t)d.B * H * 4);
     w.dgt = take(2 * H * d.A * 4);                      // dGt[H][A], then (contiguous: one all-reduce bucket under DP)
     w.dagt = w.dgt + H * d.A * 4;                       // dGgt[H][A] = one-hot(aid)^T dSh, transposed
+    w.dgtT = take((size_t)2 * d.A * pad_to(d.H, 4) * 4);
+    w.w1aT = take((size_t)2 * d.da * pad_to(d.H, 32) * 4);
     w.partial = take((size_t)NCX_COLSUM_CHUNKS * H * 4 * 2 + (size_t)NCX_COLSUM_CHUNKS * 4 + 256);
     GemmUse u[U_COUNT];
     list_uses(d, u);
@@ -1139,6 +1198,10 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
     const float* mx = (const float*)(ws + w.mx); const float* inv = (const float*)(ws + w.inv);
     const float* misc = (const float*)(ws + w.misc); const float* gt = (const float*)(ws + w.gt);
     float* dsh = (float*)(ws + w.dsh); float* dgt = (float*)(ws + w.dgt); float* dagt = (float*)(ws + w.dagt);
+    const bool emb_nt = aemb && !(d.flags & NCX_F_BF16) && !hook_env("NCX_NO_EMB_NT");   // answer-embedding gradient in NT form on the fused forward kernel
+    const int Hp4 = pad_to(H, 4), Hp32 = pad_to(H, 32);
+    float* dgtT = (float*)(ws + w.dgtT); float* dagtT = dgtT + (size_t)d.A * Hp4;
+    float* w1akT = (float*)(ws + w.w1aT); float* w1agtT = w1akT + (size_t)d.da * Hp32;
     float* partial = (float*)(ws + w.partial); float* slab = (float*)(ws + w.slab);
     (void)gt;
     GemmUse u[U_COUNT];
@@ -1170,7 +1233,8 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
         float* part_b = partial + (size_t)NCX_COLSUM_CHUNKS * H * 2;
         const bool fuse_l1 = d.L == 1;
         hipLaunchKernelGGL(k_bwd_prelude, dim3(nblk), dim3(256), 0, s, dscores, p->w_out, hL, dpre, fuse_l1 ? dsh : (float*)nullptr,
-                           d.B, d.K, H, dscale, part_w, part_b1, part_b, aemb ? dagt : (float*)nullptr, (long long)H * d.A);
+                           d.B, d.K, H, dscale, part_w, part_b1, part_b,
+                           emb_nt ? dagtT : aemb ? dagt : (float*)nullptr, emb_nt ? (long long)d.A * Hp4 : (long long)H * d.A);
         NCX_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_bwd_prelude_finish, dim3((unsigned)cdiv(H, 8), fuse_l1 ? 2 : 1), dim3(256), 0, s, (const float*)part_w,
                            (const float*)part_b1, (const float*)part_b, nblk, H, g->w_out, fuse_l1 ? g->b1 : (float*)nullptr, g->b_out);
@@ -1276,13 +1340,37 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
             rc = run_gemm(U_DW1AK, a, FORM_NN, u[U_DW1AK].plan, ss ? (float*)(ws + w.slab2) : slab,
                           ss ? w.slab2_bytes : w.slab_bytes, nullptr, ss ? ss->s : s); if (rc) return rc;
         }
-        if (do1) {   // dGgt = one-hot(aid)^T dSh   (dGgt was cleared by k_bwd_prelude)
+        if (do1 && emb_nt) {   // dGgt^T, dGt^T and the transposed weight slices for the NT embedding gradient
+            EmbPrepArgs ea{};
+            ea.dsh = dsh; ea.aid = in->answer_aids; ea.dggtT = dagtT; ea.B = d.B; ea.H = H; ea.A = d.A; ea.Hp4 = Hp4;
+            const float* srcs[3] = {dgt, p->w1 + o.a_other, p->w1 + o.a_gt};
+            float* dsts[3] = {dgtT, w1akT, w1agtT};
+            const long long ldss[3] = {d.A, din, din};
+            const int colss[3] = {d.A, d.da, d.da}, ldds[3] = {Hp4, Hp32, Hp32};
+            int tiles = 0;
+            for (int e = 0; e < 3; ++e) {
+                ea.src[e] = srcs[e]; ea.dst[e] = dsts[e]; ea.lds_[e] = ldss[e]; ea.cols[e] = colss[e]; ea.ldd[e] = ldds[e]; ea.dcols[e] = ldds[e];
+                ea.tile0[e] = tiles; tiles += ((ldds[e] + 31) / 32) * ((colss[e] + 31) / 32);
+            }
+            ea.tile0[3] = tiles;
+            hipLaunchKernelGGL(k_emb_prep, dim3(d.B + tiles), dim3(256), 0, s, ea);
+            NCX_HIP_TRY(hipGetLastError());
+        } else if (do1) {   // dGgt = one-hot(aid)^T dSh   (dGgt was cleared by k_bwd_prelude)
             hipLaunchKernelGGL(k_scatter_dsh_by_answer, dim3(d.B), dim3(256), 0, s, (const float*)dsh, in->answer_aids, d.B, H, d.A, dagt);
             NCX_HIP_TRY(hipGetLastError());
         }
         if (((do1 && !skip_de) || only_de) && bf16e) {
             rc = prof_open(U_DE, s); if (rc) return rc;
             rc = bf16_de(d, bm, dgt, g->answer_embedding, s); if (rc) return rc;
+            rc = prof_close(U_DE, s); if (rc) return rc;
+        } else if (((do1 && !skip_de) || only_de) && emb_nt) {   // dE = dGt^T . (W1ak^T)^T + dGgt^T . (W1agt^T)^T on the fused forward kernel
+            MainArgs a{}; a.M = d.A; a.N = d.da; a.nseg = 2;
+            a.seg[0].kind = MK_PLAIN; a.seg[0].a = dgtT;  a.seg[0].lda = Hp4; a.seg[0].klen = Hp4; a.seg[0].b = w1akT;  a.seg[0].ldb = Hp32;
+            a.seg[1].kind = MK_PLAIN; a.seg[1].a = dagtT; a.seg[1].lda = Hp4; a.seg[1].klen = Hp4; a.seg[1].b = w1agtT; a.seg[1].ldb = Hp32;
+            a.out = g->answer_embedding; a.ldo = d.da;
+            a.split = 1;
+            rc = prof_open(U_DE, s); if (rc) return rc;
+            rc = main_forward(a, s); if (rc) return rc;
             rc = prof_close(U_DE, s); if (rc) return rc;
         } else if ((do1 && !skip_de) || only_de) {   // dE[a][j] = sum_n dGt[n][a] W1ak[n][j] + sum_n dGgt[n][a] W1agt[n][j]
             GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 2; a.M = d.A;
@@ -1308,8 +1396,8 @@ int ncx_ws_region(const ncx_dims* dp, int32_t which, size_t* offset, size_t* byt
         *bytes = (size_t)dp->B * dp->K * dp->H * 4;
         return NCX_OK;
     }
-    *offset = w.dgt;
-    *bytes = (dp->flags & NCX_F_A_EMB) ? (size_t)2 * dp->H * dp->A * 4 : 0;
+    if (dp->flags & NCX_F_BF16) { *offset = w.dgt; *bytes = (dp->flags & NCX_F_A_EMB) ? (size_t)2 * dp->H * dp->A * 4 : 0; }
+    else { *offset = w.dgtT; *bytes = (dp->flags & NCX_F_A_EMB) ? (size_t)2 * dp->A * pad_to(dp->H, 4) * 4 : 0; }   // dGt^T | dGgt^T
     return NCX_OK;
 }
 

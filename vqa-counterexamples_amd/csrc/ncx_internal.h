@@ -52,7 +52,9 @@ struct WsLayout {
     size_t dpre[2];                     // [M][H] ping-pong of pre-activation gradients
     size_t dsh;                         // [B][H]
     size_t dgt;                         // [H][A]
-    size_t dagt;                        // dGgt [H][A]
+    size_t dagt;                        // dGgt [H][A]  (bf16 variant only; the fp32 path keeps it transposed, below)
+    size_t dgtT;                        // fp32 path: dGt^T [A][Hp4] then dGgt^T [A][Hp4] (contiguous: the all-reduce bucket under DP); Hp4 = H up to a multiple of 4
+    size_t w1aT;                        // fp32 path: W1[:, a_other]^T then W1[:, a_gt]^T, [da][Hp32] each (zero padded)
     size_t partial;                     // column-sum partials [NCX_COLSUM_CHUNKS][H] x 2 + scalars
     size_t slab;                        // split-K slabs (max over all uses)
     size_t slab_bytes;

@@ -465,79 +465,80 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
     // ---- epilogue: + Sh[r / K] (+ bias), ReLU, Dropout, store ---------------------------------------------------------
     // Every operand is fetched behind one uniform test per kind (a test per element puts each load in its own basic block:
     // 24 serialised round trips); r / K of a lane's 4 consecutive rows comes from ONE division.
-    if (S > 1) {                                         // raw partial sums -> slab[z]; the epilogue runs in k_main_fixup
-        float* const slab = args.slab + (long long)z * M * N;
+    // The finished tile goes to memory through LDS.  The accumulator layout gives every lane 4 rows x 1 column per block, so an
+    // in-register epilogue is WM * WN * 4 unrolled copies of (row add, bias, ReLU, dropout hash, scalar store): 6-12 KB of code
+    // that each workgroup runs once -- in-kernel stamps put it at 13-17k cycles, mostly instruction fetch.  Instead the raw
+    // accumulators are staged in LDS (WM * WN * 4 ds_write_b32) and ONE rolled loop over 16-byte row pieces applies the
+    // epilogue with 16-byte operand loads and stores whole rows.
+    constexpr int SP = BN + 4;
+    float* const stage = mf_smem;                        // [BM][SP]  (every fragment read is complete: the last step's barrier)
 #pragma unroll
-        for (int i = 0; i < WM; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                const int n = n0 + wn0 + 16 * j + li;
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int r = m0 + wm0 + 16 * i + 4 * lk + q;
-                    if (r < M && n < N) slab[(long long)r * N + n] = acc[i][j][q];
-                }
-            }
-        return;
-    }
+            for (int q = 0; q < 4; ++q) stage[(wm0 + 16 * i + 4 * lk + q) * SP + wn0 + 16 * j + li] = acc[i][j][q];
+    __syncthreads();
+    constexpr int QR = BN / 4;                            // 16-byte pieces per tile row
     const EpiArgs& e = args.epi;
-    const int rdiv = e.rowadd ? e.rowdiv : 1;
+    float* const dst = S > 1 ? args.slab + (long long)z * M * N : args.out;      // S > 1: raw partial sums; k_main_fixup runs the epilogue
+    const long long ldd = S > 1 ? (long long)N : args.ldo;
+    const bool plain = S > 1 || !(e.rowadd || e.bias || e.relu || e.dropout || e.gate);
+    // (the row-add operand of piece f + 256 is fetched while piece f is finished: rolled, but never waiting on its own load)
+    auto item = [&](int f, int& r, int& n, int& nl) __attribute__((always_inline)) {
+        const int rr = f / QR, cq = f - rr * QR;
+        r = m0 + rr; n = n0 + 4 * cq;
+        nl = min(n, N - 4 >= 0 ? N - 4 : 0);                               // operand window slid left at the right edge (N >= 4)
+        return rr * SP + 4 * cq;
+    };
+    auto win = [&](const float* p, int nl, int sh) __attribute__((always_inline)) {   // p[n .. n+3] (zero beyond N) from a 16-byte load at nl
+        const f32x4 w = *(const f32x4u*)(p + nl);
+        f32x4 o;
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
-        float addv[WN][4], maskv[WN][4], gatev[WN][4], bias_v[WN];
-        int nc[WN];
-#pragma unroll
-        for (int j = 0; j < WN; ++j) nc[j] = min(n0 + wn0 + 16 * j + li, N - 1);
-        const int rb = m0 + wm0 + 16 * i + 4 * lk;                     // first of this lane's 4 rows
-        const int q0 = rb / rdiv, rem0 = rb - q0 * rdiv;
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            bias_v[j] = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { addv[j][q] = 0.f; maskv[j][q] = 1.f; gatev[j][q] = 1.f; }
+        for (int jj = 0; jj < 4; ++jj) o[jj] = jj + sh < 4 ? (sh == 0 ? w[jj] : sh == 1 ? w[(jj + 1) & 3] : sh == 2 ? w[(jj + 2) & 3] : w[(jj + 3) & 3]) : 0.f;
+        return o;
+    };
+    const bool use_add = !plain && e.rowadd;
+    const int rdiv = use_add ? e.rowdiv : 1;
+    f32x4 add_next = {0.f, 0.f, 0.f, 0.f};
+    {
+        int r, n, nl; item(tid, r, n, nl);
+        if (use_add) add_next = win(e.rowadd + (long long)(min(r, M - 1) / rdiv) * e.ld_rowadd, min(nl, max(N - 4, 0)), min(n, N - 1) - min(nl, max(N - 4, 0)));
+    }
+#pragma unroll 1
+    for (int f = tid; f < BM * QR; f += MF_T) {
+        int r, n, nl;
+        const int so = item(f, r, n, nl);
+        const f32x4 addv = add_next;
+        if (use_add && f + MF_T < BM * QR) {
+            int r2, n2, nl2; item(f + MF_T, r2, n2, nl2);
+            const int n2c = min(n2, N - 1), nl2c = min(nl2, n2c);
+            add_next = win(e.rowadd + (long long)(min(r2, M - 1) / rdiv) * e.ld_rowadd, nl2c, n2c - nl2c);
         }
-        if (e.bias) {
+        if (r >= M || n >= N) continue;
+        f32x4 v = *(const f32x4*)(stage + so);
+        const int sh = n - nl;
+        if (!plain) {
+            f32x4 add = addv, msk = {1.f, 1.f, 1.f, 1.f}, gte = {1.f, 1.f, 1.f, 1.f};
+            if (e.bias) add += win(e.bias, nl, sh);
+            if (e.dropout == 2) msk = win(e.keep_mask + (long long)r * e.ld_mask, nl, sh);
+            if (e.gate) gte = win(e.gate + (long long)r * e.ld_gate, nl, sh);
 #pragma unroll
-            for (int j = 0; j < WN; ++j) bias_v[j] = e.bias[nc[j]];
-        }
-        if (e.rowadd) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int t = rem0 + q;                                  // < rdiv + 3: at most one wrap (rdiv >= 3)
-                const int bq = min(q0 + (t >= rdiv ? 1 : 0), (M - 1) / rdiv);
-#pragma unroll
-                for (int j = 0; j < WN; ++j) addv[j][q] = e.rowadd[(long long)bq * e.ld_rowadd + nc[j]];
-            }
-        }
-        if (e.dropout == 2) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int j = 0; j < WN; ++j) maskv[j][q] = e.keep_mask[(long long)min(rb + q, M - 1) * e.ld_mask + nc[j]];
-        }
-        if (e.gate) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int j = 0; j < WN; ++j) gatev[j][q] = e.gate[(long long)min(rb + q, M - 1) * e.ld_gate + nc[j]];
-        }
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int n = n0 + wn0 + 16 * j + li;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int r = rb + q;
-                float v = acc[i][j][q] + addv[j][q] + bias_v[j];
-                if (e.relu == 1) v = v > 0.f ? v : 0.f;
-                else if (e.relu == 2) v = tanhf(v);
+            for (int jj = 0; jj < 4; ++jj) {
+                float x = v[jj] + add[jj];
+                if (e.relu == 1) x = x > 0.f ? x : 0.f;
+                else if (e.relu == 2) x = tanhf(x);
                 if (e.dropout == 1)
-                    v = dropout_keep(e.seed_lo, e.seed_hi, e.layer, (unsigned long long)r * (unsigned)N + (unsigned)n, e.drop_p) ? v * e.drop_scale : 0.f;
+                    x = dropout_keep(e.seed_lo, e.seed_hi, e.layer, (unsigned long long)r * (unsigned)N + (unsigned)(n + jj), e.drop_p) ? x * e.drop_scale : 0.f;
                 else if (e.dropout == 2)
-                    v = maskv[j][q] != 0.f ? v * e.drop_scale : 0.f;
-                if (e.gate) v = gatev[j][q] > 0.f ? v * e.gate_scale : 0.f;
-                if (r < M && n < N) args.out[(long long)r * args.ldo + n] = v;
+                    x = msk[jj] != 0.f ? x * e.drop_scale : 0.f;
+                if (e.gate) x = gte[jj] > 0.f ? x * e.gate_scale : 0.f;
+                v[jj] = x;
             }
         }
+        float* o = dst + (long long)r * ldd + n;
+        if (n + 3 < N) *(f32x4u*)o = v;
+        else { o[0] = v[0]; if (n + 1 < N) o[1] = v[1]; if (n + 2 < N) o[2] = v[2]; }
     }
     stamp(8);
     if (stamps && tid == 0) stamps[15] = __builtin_amdgcn_s_memrealtime();
@@ -622,6 +623,7 @@ static inline int launch_main_fwd(MainArgs& a, hipStream_t s) {
     if (is({G, P, P, S}))    return launch_main_fwd_seq<CFG, false, G, P, P, S>(a, s);
     if (is({G, X, P, P, P})) return launch_main_fwd_seq<CFG, false, G, X, P, P, P>(a, s);
     if (is({G, P, P, P}))    return launch_main_fwd_seq<CFG, false, G, P, P, P>(a, s);
+    if (is({P, P}))          return launch_main_fwd_seq<CFG, false, P, P>(a, s);
     return NCX_E_FLAGS;
 }
 

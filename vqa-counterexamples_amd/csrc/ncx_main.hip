@@ -6,6 +6,7 @@ namespace ncx {
 typedef MainCfg<48, 128, 1, 4, 2, 2> MainCfg0;      // two workgroups per CU, 48 x 128 tiles (2 triplets at K = 24), loads two k-steps ahead
 typedef MainCfg<96, 64, 2, 2, 1, 2> MainCfg1;
 typedef MainCfg<96, 128, 2, 2, 2, 1> MainCfg2;      // one workgroup per CU with the whole register file
+typedef MainCfg<64, 64, 2, 2, 2, 3> MainCfg3;       // short chains (the answer-embedding gradient: 16 k-steps): three small workgroups per CU
 typedef MainCfg<48, 64, 1, 4, 2, 2> MainCfgFold;    // MK_VFOLD sequences: 48 x 64 tiles (two triplets), two workgroups per CU
 
 // Measured inside the training step at configs[1] (B = 512: 256 tiles of 96 x 128): 338 us with one 96 x 128 workgroup per CU,
@@ -14,6 +15,10 @@ typedef MainCfg<48, 64, 1, 4, 2, 2> MainCfgFold;    // MK_VFOLD sequences: 48 x 
 // batches (data-parallel shards: 64 triplets per GPU) take the 48-row tile: twice the workgroups.
 int main_forward(MainArgs& a, hipStream_t s) {
     if (a.nseg > 0 && a.seg[0].kind == MK_VFOLD) return launch_main_fwd<MainCfgFold>(a, s);
+    long long T = 0;
+    for (int i = 0; i < a.nseg; ++i) T += (a.seg[i].klen + MF_BK - 1) / MF_BK;
+    if (a.split <= 1 && T <= 32 && (long long)((a.M + 63) / 64) * ((a.N + 63) / 64) >= 2 * num_cus() && !hook_env("NCX_MAIN_CFG"))
+        return launch_main_fwd<MainCfg3>(a, s);          // a workgroup that short spends as long starting and storing as multiplying: more of them per CU
     const long long tiles96 = (long long)((a.M + 95) / 96) * ((a.N + 127) / 128);
     int cfg = (a.split <= 1 && tiles96 * 10 >= (long long)num_cus() * 9) ? 2 : 0;
     if (const char* e = hook_env("NCX_MAIN_CFG")) cfg = atoi(e);       // experiment hook (NCX_EXPERIMENT=1)
