@@ -176,6 +176,34 @@ int main(int argc, char** argv) {
         printf("-- short chain (dE shape)\n");
         tm("48x128 d2 o2", C_48_128_d2_o2{}); tm("96x128 d2 o1", C_96_128_d2_o1{}); tm("96x64 d1 o2", C_96_64_d1_o2{}); tm("64x64 d2 o3", C_64_64_d2_o3{});
     }
+    {   // the Gt shape (M 256, N 2000, K 2400, one plain segment) with a k-split: fused forward kernel + fix-up
+        const int Mg = 256, Ng = 2000, Kg = 2400;
+        float* gA = dev_rand((size_t)Mg * Kg, 1.f, 41); float* gB = dev_rand((size_t)Ng * Kg, 0.05f, 42);
+        float* gout; CHECK(hipMalloc(&gout, (size_t)Mg * 2016 * 4));
+        float* gslab; CHECK(hipMalloc(&gslab, (size_t)16 * Mg * Ng * 4));
+        MainArgs b{}; b.M = Mg; b.N = Ng; b.nseg = 1; b.out = gout; b.ldo = 2016; b.slab = gslab;
+        b.seg[0].kind = MK_PLAIN; b.seg[0].a = gA; b.seg[0].lda = Kg; b.seg[0].klen = Kg; b.seg[0].b = gB; b.seg[0].ldb = Kg;
+        printf("-- Gt shape, fused forward kernel + fix-up (generic engine in the step: 41 us)\n");
+        auto tm = [&](const char* nm, auto cfg_c, int split) {
+            typedef decltype(cfg_c) C;
+            hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+            MainArgs c = b; c.split = split;
+            for (int i = 0; i < 3; ++i) launch_main_fwd<C>(c, 0);
+            CHECK(hipEventRecord(e0, 0)); for (int i = 0; i < 10; ++i) launch_main_fwd<C>(c, 0); CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            printf("   %-14s split %2d  %6.1f us\n", nm, split, ms * 100);
+        };
+        for (int sp : {3, 4, 6}) { tm("64x64 d2 o3", C_64_64_d2_o3{}, sp); tm("48x128 d2 o2", C_48_128_d2_o2{}, sp); tm("96x64 d1 o2", C_96_64_d1_o2{}, sp); }
+        // the Sh shape: M 512, N 256, K 7208 (one plain segment stands in for the four)
+        const int Ms = 512, Ns = 256, Ksh = 7208;
+        float* hA = dev_rand((size_t)Ms * Ksh, 1.f, 43); float* hB = dev_rand((size_t)Ns * 7232, 0.05f, 44);
+        float* hslab; CHECK(hipMalloc(&hslab, (size_t)32 * Ms * Ns * 4));
+        MainArgs h{}; h.M = Ms; h.N = Ns; h.nseg = 1; h.out = gout; h.ldo = Ns; h.slab = hslab;
+        h.seg[0].kind = MK_PLAIN; h.seg[0].a = hA; h.seg[0].lda = Ksh; h.seg[0].klen = Ksh; h.seg[0].b = hB; h.seg[0].ldb = 7232;
+        b = h;
+        printf("-- Sh shape (generic engine in the step: 38 us)\n");
+        for (int sp : {12, 16, 24}) { tm("64x64 d2 o3", C_64_64_d2_o3{}, sp); tm("48x128 d2 o2", C_48_128_d2_o2{}, sp); }
+    }
     {   // in-kernel stamps of one launch of the library's configuration: where does a workgroup's time go?
         typedef C_48_128_d2_o2 C;
         const int tiles_m = (M + C::BM - 1) / C::BM, tiles_n = (H + C::BN - 1) / C::BN, grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
