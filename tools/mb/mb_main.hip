@@ -235,5 +235,38 @@ int main(int argc, char** argv) {
         // a few individual timelines
         for (int g : {0, 1, 8, 255, 256, 511}) if (g < grid && h[g * 16 + 15]) printf("   wg %3d xcd %llu start +%.1f us dur %.1f us\n", g, h[g * 16 + 13] & 7, (h[g * 16 + 14] - r0) / 100.0, (h[g * 16 + 15] - h[g * 16 + 14]) / 100.0);
     }
+    {   // in-kernel stamps of one launch of the library's configuration: where does a workgroup's time go?
+        typedef MainCfg<48, 64, 1, 4, 2, 2> C;
+        const int tiles_m = (M + C::BM - 1) / C::BM, tiles_n = (H + C::BN - 1) / C::BN, grid = ((tiles_m + 7) / 8) * 8 * tiles_n;
+        unsigned long long* st; CHECK(hipMalloc(&st, (size_t)grid * 16 * 8)); CHECK(hipMemset(st, 0, (size_t)grid * 16 * 8));
+        Problem pf = p; pf.full.seg[0].kind = MK_VFOLD; pf.full.seg[0].idx2 = idx_o; pf.full.seg[0].b2 = p.full.seg[1].b;
+        pf.full.seg[1] = p.full.seg[2]; pf.full.seg[2] = p.full.seg[3]; pf.full.seg[3] = p.full.seg[4]; pf.full.nseg = 4;
+        MainArgs b = pf.full; b.stamps = st;
+        for (int i = 0; i < 3; ++i) launch_main_fwd<C>(b, 0);
+        CHECK(hipDeviceSynchronize());
+        std::vector<unsigned long long> h((size_t)grid * 16);
+        CHECK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long r0 = ~0ull, r1 = 0;
+        for (int g = 0; g < grid; ++g) { if (!h[g * 16 + 15]) continue; r0 = h[g * 16 + 14] < r0 ? h[g * 16 + 14] : r0; r1 = h[g * 16 + 15] > r1 ? h[g * 16 + 15] : r1; }
+        printf("-- stamps (FOLD 48x64): kernel span %.1f us (first start .. last end, 100 MHz counter)\n", (r1 - r0) / 100.0);
+        double sum[10] = {0}, mx_start = 0, mn_dur = 1e30, mx_dur = 0, clk = 0; int cnt = 0; int per_xcd[8] = {0};
+        for (int g = 0; g < grid; ++g) {
+            const unsigned long long* w = &h[g * 16]; if (!w[15]) continue;
+            const double start = (w[14] - r0) / 100.0, dur = (w[15] - w[14]) / 100.0;
+            mx_start = start > mx_start ? start : mx_start; mn_dur = dur < mn_dur ? dur : mn_dur; mx_dur = dur > mx_dur ? dur : mx_dur;
+            clk += (double)(w[8] - w[0]) / ((w[15] - w[14]) * 10.0);      // cycles per ns -> GHz
+            for (int i = 0; i < 4; ++i) sum[i] += (double)(w[1 + i] - w[i]);
+            sum[5] += (double)(w[8] - w[4]);
+            per_xcd[w[13] & 7]++; ++cnt;
+        }
+        printf("   workgroups %d  latest start +%.1f us  duration min %.1f max %.1f us  mean clock %.2f GHz  per-XCD", cnt, mx_start, mn_dur, mx_dur, clk / cnt);
+        for (int x = 0; x < 8; ++x) printf(" %d", per_xcd[x]);
+        printf("\n");
+        const char* nm[6] = {"fold(v)", "misc", "z", "softmax", "-", "epilogue"};
+        const int ks[6] = {64, 1, 12, 63, 1, 1};
+        for (int i = 0; i < 6; ++i) printf("   %-10s mean %9.0f cycles  (%7.0f per k-step; 48 MFMAs x 32 = 1536 issue cycles per wave, x2 workgroups per SIMD = 3072)\n", nm[i], sum[i] / cnt, sum[i] / cnt / ks[i]);
+        // a few individual timelines
+        for (int g : {0, 1, 8, 255, 256, 511}) if (g < grid && h[g * 16 + 15]) printf("   wg %3d xcd %llu start +%.1f us dur %.1f us\n", g, h[g * 16 + 13] & 7, (h[g * 16 + 14] - r0) / 100.0, (h[g * 16 + 15] - h[g * 16 + 14]) / 100.0);
+    }
     return 0;
 }
