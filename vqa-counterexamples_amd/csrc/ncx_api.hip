@@ -89,6 +89,16 @@ __global__ __launch_bounds__(256) void k_prep(ncx_dims d, ncx_inputs in, int* __
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
     const int b = r / d.K, k = r - b * d.K;
+    // RESIDENT: every row load is an UNCONDITIONAL 16-byte window (slid left at the row end, repaired below); the guarded form
+    // put each load in its own basic block behind an s_waitcnt vmcnt(0): 24 serialised round trips per row, 2 TB/s.
+    // The answer-logit row needs no index, so its loads go first; the two feature rows follow their indices.
+    const bool aemb_ = d.flags & NCX_F_A_EMB;
+    f32x4 ra[NR];
+    if (RESIDENT && aemb_) {
+        const float* arow = in.a_knns + (long long)r * d.A;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) ra[i] = load_window(arow, lane * 4 + 256 * i, d.A);
+    }
     const int io = in.img_idx[(long long)b * (d.K + 1)];
     const int ik = in.img_idx[(long long)b * (d.K + 1) + 1 + k];
     if (lane == 0) { idx_o[r] = io; idx_k[r] = ik; if (k == 0) idx_ob[b] = io; }
@@ -101,7 +111,11 @@ __global__ __launch_bounds__(256) void k_prep(ncx_dims d, ncx_inputs in, int* __
     f32x4 ro[NR], rk[NR];
     if (RESIDENT && need_v) {
 #pragma unroll
-        for (int i = 0; i < NR; ++i) { ro[i] = load4(vo, lane * 4 + 256 * i, d.dv); rk[i] = load4(vk, lane * 4 + 256 * i, d.dv); }
+        for (int i = 0; i < NR; ++i) { ro[i] = load_window(vo, lane * 4 + 256 * i, d.dv); rk[i] = load_window(vk, lane * 4 + 256 * i, d.dv); }
+        if (d.dv % 256 != 0) {                     // (uniform: whole 256-column passes need no repair)
+#pragma unroll
+            for (int i = 0; i < NR; ++i) { ro[i] = fix_window(ro[i], lane * 4 + 256 * i, d.dv); rk[i] = fix_window(rk[i], lane * 4 + 256 * i, d.dv); }
+        }
     }
     auto v_at = [&](int i, int c, f32x4& a, f32x4& e) __attribute__((always_inline)) {
         if (RESIDENT) { a = ro[i]; e = rk[i]; } else { a = load4(vo, c, d.dv); e = load4(vk, c, d.dv); }
@@ -170,10 +184,9 @@ __global__ __launch_bounds__(256) void k_prep(ncx_dims d, ncx_inputs in, int* __
 
     if (d.flags & NCX_F_A_EMB) {
         const float* a = in.a_knns + (long long)r * d.A;
-        f32x4 ra[NR];
-        if (RESIDENT) {
+        if (RESIDENT && d.A % 256 != 0) {
 #pragma unroll
-            for (int i = 0; i < NR; ++i) ra[i] = load4(a, lane * 4 + 256 * i, d.A);
+            for (int i = 0; i < NR; ++i) ra[i] = fix_window(ra[i], lane * 4 + 256 * i, d.A);
         }
         float m = -INFINITY;
         if (RESIDENT) {
@@ -367,10 +380,12 @@ __global__ __launch_bounds__(256) void k_sum_vec(const float* __restrict__ x, in
     if (threadIdx.x == 0) out[0] = sl[0] + sl[1] + sl[2] + sl[3];
 }
 
-// Backward prelude in one pass over h_L (thread = column n, block = a run of triplets):
+// Backward prelude in one pass over h_L.  One WAVE per run of triplets, lane = 4 consecutive columns (+ 256 per column pass):
 //   dpre[r][n] = gs[r] * w_out[n] * (h[r][n] > 0 ? scale : 0)                    (out + dropout + relu backward)
-//   partial_w[blk][n] = sum_r gs[r] h[r][n]    partial_b[blk] = sum_r gs[r]       (-> d out.weight, d out.bias)
-//   L == 1 only: dsh[b][n] = sum_k dpre[b*K+k][n],  partial_b1[blk][n] = sum_b dsh[b][n]   (-> d linear_1.bias)
+//   partial_w[wave][n] = sum_r gs[r] h[r][n]    partial_b[wave] = sum_r gs[r]     (-> d out.weight, d out.bias)
+//   L == 1 only: dsh[b][n] = sum_k dpre[b*K+k][n],  partial_b1[wave][n] = sum_b dsh[b][n]   (-> d linear_1.bias)
+// The K rows of a triplet are fetched 8 at a time with unconditional 16-byte loads (the column-per-thread form walked them one
+// dependent load at a time on 4 waves per CU: 18.7 us for 28 MB at configs[1]); no LDS, no barrier: a lane owns its columns.
 __global__ __launch_bounds__(256) void k_bwd_prelude(const float* __restrict__ gs, const float* __restrict__ w_out,
                                                      const float* __restrict__ h, float* __restrict__ dpre,
                                                      float* __restrict__ dsh, int B, int K, int H, float scale,
@@ -384,31 +399,47 @@ __global__ __launch_bounds__(256) void k_bwd_prelude(const float* __restrict__ g
             else for (long long j = i; j < z1; ++j) zero_buf[j] = 0.f;
         }
     }
-    const int b0 = (int)((long long)B * blk / nblk), b1 = (int)((long long)B * (blk + 1) / nblk);
-    for (int n = threadIdx.x; n < H; n += 256) {
-        const float w = w_out[n];
-        float aw = 0.f, ab1 = 0.f;
+    const int lane = threadIdx.x & 63;
+    const int wv = blk * 4 + (threadIdx.x >> 6), nwv = nblk * 4;
+    const int b0 = (int)((long long)B * wv / nwv), b1 = (int)((long long)B * (wv + 1) / nwv);
+    auto put4 = [&](float* p, int c, const f32x4& v) __attribute__((always_inline)) {
+        if (c + 3 < H) *(f32x4u*)(p + c) = v;
+        else { p[c] = v[0]; if (c + 1 < H) p[c + 1] = v[1]; if (c + 2 < H) p[c + 2] = v[2]; }
+    };
+    for (int c = lane * 4; c < H; c += 256) {
+        const bool edge = c + 4 > H;
+        const f32x4 w = fix_window(load_window(w_out, c, H), c, H);
+        f32x4 aw = {0.f, 0.f, 0.f, 0.f}, ab1 = {0.f, 0.f, 0.f, 0.f};
         for (int b = b0; b < b1; ++b) {
-            float ds = 0.f;
             const long long r0 = (long long)b * K;
-            for (int k = 0; k < K; ++k) {
-                const float g = gs[r0 + k];
-                const float hv = h[(r0 + k) * H + n];
-                const float dp = hv > 0.f ? g * w * scale : 0.f;
-                dpre[(r0 + k) * H + n] = dp;
-                aw += g * hv;
-                ds += dp;
+            f32x4 ds = {0.f, 0.f, 0.f, 0.f};
+            for (int k0 = 0; k0 < K; k0 += 8) {
+                f32x4 hv[8]; float g[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const long long r = r0 + min(k0 + j, K - 1);
+                    hv[j] = load_window(h + r * H, c, H);
+                    g[j] = k0 + j < K ? gs[r] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (k0 + j >= K) break;
+                    const f32x4 v = edge ? fix_window(hv[j], c, H) : hv[j];
+                    f32x4 dp;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { dp[q] = v[q] > 0.f ? g[j] * w[q] * scale : 0.f; aw[q] += g[j] * v[q]; ds[q] += dp[q]; }
+                    put4(dpre + (r0 + k0 + j) * H, c, dp);
+                }
             }
-            if (dsh) { dsh[(long long)b * H + n] = ds; ab1 += ds; }
+            if (dsh) { put4(dsh + (long long)b * H, c, ds); ab1 += ds; }
         }
-        partial_w[(long long)blk * H + n] = aw;
-        if (dsh) partial_b1[(long long)blk * H + n] = ab1;
+        put4(partial_w + (long long)wv * H, c, aw);
+        if (dsh) put4(partial_b1 + (long long)wv * H, c, ab1);
     }
-    if (threadIdx.x == 0) {
-        float s = 0.f;
-        for (long long r = (long long)b0 * K; r < (long long)b1 * K; ++r) s += gs[r];
-        partial_b[blk] = s;
-    }
+    float s = 0.f;
+    for (long long r = (long long)b0 * K + lane; r < (long long)b1 * K; r += 64) s += gs[r];
+    s = wave_sum(s);
+    if (lane == 0) partial_b[wv] = s;
 }
 // out_w[n] = sum_blk partial_w[blk][n]; out_b1[n] likewise (nullable); out_b[0] = sum_blk partial_b[blk]
 __global__ __launch_bounds__(256) void k_bwd_prelude_finish(const float* __restrict__ partial_w, const float* __restrict__ partial_b1,
@@ -431,9 +462,10 @@ __global__ __launch_bounds__(256) void k_bwd_prelude_finish(const float* __restr
         for (int i = 0; i < 32; ++i) t += red[i][c];
         out[n] = t;
     }
-    if (which == 0 && blockIdx.x == 0) {              // d out.bias: nblk <= 256 partials, fixed-order tree
+    if (which == 0 && blockIdx.x == 0) {              // d out.bias: fixed-order tree over the partials
         __shared__ float sb[4];
-        float v = (int)threadIdx.x < nblk ? partial_b[threadIdx.x] : 0.f;
+        float v = 0.f;
+        for (int i = threadIdx.x; i < nblk; i += 256) v += partial_b[i];
         v = wave_sum(v);
         if ((threadIdx.x & 63) == 0) sb[threadIdx.x >> 6] = v;
         __syncthreads();
@@ -785,17 +817,18 @@ WsLayout ws_layout(const ncx_dims& d) {
     w.dagt = w.dgt + H * d.A * 4;                       // dGgt[H][A] = one-hot(aid)^T dSh, transposed
     w.dgtT = take((size_t)2 * d.A * pad_to(d.H, 4) * 4);
     w.w1aT = take((size_t)2 * d.da * pad_to(d.H, 32) * 4);
-    w.partial = take((size_t)NCX_COLSUM_CHUNKS * H * 4 * 2 + (size_t)NCX_COLSUM_CHUNKS * 4 + 256);
+    w.partial = take((size_t)NCX_PRELUDE_WAVES * H * 4 * 2 + (size_t)NCX_PRELUDE_WAVES * 4 + 256);     // (>= NCX_COLSUM_CHUNKS rows)
     GemmUse u[U_COUNT];
     list_uses(d, u);
     long long slab = 0;
     for (int i = 0; i < U_COUNT; ++i) slab = u[i].slab_elems > slab ? u[i].slab_elems : slab;
     w.slab_bytes = (size_t)slab * 4;
     w.slab = take(w.slab_bytes);
-    {   // side-stream GEMMs (Gt, Sh forward; dW1ak backward) get their own slab
+    {   // side-stream GEMMs (Gt, Sh forward; dW1ak, dE backward) get their own slab
         long long s2 = u[U_GT].slab_elems;
         if (u[U_SH].slab_elems > s2) s2 = u[U_SH].slab_elems;
         if (u[U_DW1AK].slab_elems > s2) s2 = u[U_DW1AK].slab_elems;
+        if (u[U_DE].slab_elems > s2) s2 = u[U_DE].slab_elems;
         w.slab2_bytes = (size_t)s2 * 4;
         w.slab2 = take(w.slab2_bytes);
     }
@@ -1227,17 +1260,17 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
         dpre = (float*)(ws + w.dpre[(d.L - 1) & 1]);
     } else {
         // one pass: dpre_L, d out.weight / d out.bias partials, and for L == 1 also dSh + d linear_1.bias partials
-        const int nblk = d.B < NCX_COLSUM_CHUNKS ? d.B : NCX_COLSUM_CHUNKS;
+        const int nblk = (int)cdiv(d.B < NCX_PRELUDE_WAVES ? d.B : NCX_PRELUDE_WAVES, 4);      // one wave per run of triplets
         float* part_w = partial;
-        float* part_b1 = partial + (size_t)NCX_COLSUM_CHUNKS * H;
-        float* part_b = partial + (size_t)NCX_COLSUM_CHUNKS * H * 2;
+        float* part_b1 = partial + (size_t)NCX_PRELUDE_WAVES * H;
+        float* part_b = partial + (size_t)NCX_PRELUDE_WAVES * H * 2;
         const bool fuse_l1 = d.L == 1;
         hipLaunchKernelGGL(k_bwd_prelude, dim3(nblk), dim3(256), 0, s, dscores, p->w_out, hL, dpre, fuse_l1 ? dsh : (float*)nullptr,
                            d.B, d.K, H, dscale, part_w, part_b1, part_b,
                            emb_nt ? dagtT : aemb ? dagt : (float*)nullptr, emb_nt ? (long long)d.A * Hp4 : (long long)H * d.A);
         NCX_HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(k_bwd_prelude_finish, dim3((unsigned)cdiv(H, 8), fuse_l1 ? 2 : 1), dim3(256), 0, s, (const float*)part_w,
-                           (const float*)part_b1, (const float*)part_b, nblk, H, g->w_out, fuse_l1 ? g->b1 : (float*)nullptr, g->b_out);
+                           (const float*)part_b1, (const float*)part_b, nblk * 4, H, g->w_out, fuse_l1 ? g->b1 : (float*)nullptr, g->b_out);
         NCX_HIP_TRY(hipGetLastError());
     }
     // ---- hidden layers L..2 ---------------------------------------------------------------------------
@@ -1270,6 +1303,13 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
         NCX_HIP_TRY(hipGetLastError());
         rc = colsum(dsh, nullptr, d.B, H, g->b1); if (rc) return rc;
     }
+    bool km_deferred = false;
+    auto run_km = [&]() -> int {
+        int r = prof_open(U_DW1C, s); if (r) return r;
+        r = dw_km(d, dpre, in->feats, idx_k, idx_o, (float*)(ws + w.km_slab), g->w1 + o.v_other, g->w1 + o.v_mult, din, s);
+        if (r) return r;
+        return prof_close(U_DW1C, s);
+    };
     {   // dW1 = [dpre^T . candidate segments (+ dGt) | dSh^T . shared segments]: ONE grouped launch, per-problem
         // reduction extent (M rows of dpre vs B rows of dSh) and k-split
         GemmArgs a{}; a.mode = MODE_GROUP; a.M = H;
@@ -1290,11 +1330,11 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
             rc = prof_close(U_DW1C, s); if (rc) return rc;
         }
         const bool km = dw_km_supported(d) && !bf16;
-        if (want_rest && km) {      // v_other and v_mult columns in one MFMA pass (per-triplet fold)
-            rc = prof_open(U_DW1C, s); if (rc) return rc;
-            rc = dw_km(d, dpre, in->feats, idx_k, idx_o, (float*)(ws + w.km_slab), g->w1 + o.v_other, g->w1 + o.v_mult, din, s);
-            if (rc) return rc;
-            rc = prof_close(U_DW1C, s); if (rc) return rc;
+        // With the side stream the per-triplet fold kernel (a full round of long workgroups) is launched AFTER the grouped
+        // launch, next to the answer-embedding chain (dW1ak, dE: short latency-bound workgroups) that waits for dGt.
+        km_deferred = want_rest && km && aemb && do1 && do2 && side_stream() != nullptr;
+        if (want_rest && km && !km_deferred) {      // v_other and v_mult columns in one MFMA pass (per-triplet fold)
+            rc = run_km(); if (rc) return rc;
         }
         if (want_rest && !bf16 && !km) {
             add_c(x_gather(in->feats, d.dv, idx_k, M, d.dv), g->w1 + o.v_other, din);
@@ -1323,22 +1363,23 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
         }
     }
     if (aemb) {
-        // dW1[:, a_other] = dGt . E and dE are independent consumers of dGt: when both run in this call, the former
-        // goes to the side stream (own slab) and overlaps the latter
-        SideStream* ss = (do1 && do2) ? side_stream() : nullptr;
+        // The consumers of dGt (dW1[:, a_other] = dGt . E, then dE) form a chain of short launches: with the side stream they
+        // run there (own slab) while the caller's stream runs the per-triplet fold kernel
+        SideStream* ss = km_deferred ? side_stream() : nullptr;
+        hipStream_t se = ss ? ss->s : s;
+        if (ss) { rc = side_fork(ss, s); if (rc) return rc; }
         const bool bf16e = d.flags & NCX_F_BF16;
         const Bf16Emb bm = bf16e ? bf16_emb_layout(d, ws + w.bf_emb) : Bf16Emb{};
         if (do2 && bf16e) {
-            rc = prof_open(U_DW1AK, s); if (rc) return rc;
-            rc = bf16_dw1ak(d, bm, dgt, g->w1, s); if (rc) return rc;
-            rc = prof_close(U_DW1AK, s); if (rc) return rc;
+            rc = prof_open(U_DW1AK, se); if (rc) return rc;
+            rc = bf16_dw1ak(d, bm, dgt, g->w1, se); if (rc) return rc;
+            rc = prof_close(U_DW1AK, se); if (rc) return rc;
         } else if (do2) {   // dW1[:, a_other][n][j] = sum_a dGt[n][a] E[a][j]
             GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = H;
             a.a[0] = x_plain(dgt, d.A, H, d.A); a.b[0] = x_plain(p->answer_embedding, d.da, d.A, d.da); a.klen[0] = d.A;
             a.out[0] = g->w1 + o.a_other; a.ldo[0] = din; a.n_cols[0] = d.da;
-            if (ss) { rc = side_fork(ss, s); if (rc) return rc; }
             rc = run_gemm(U_DW1AK, a, FORM_NN, u[U_DW1AK].plan, ss ? (float*)(ws + w.slab2) : slab,
-                          ss ? w.slab2_bytes : w.slab_bytes, nullptr, ss ? ss->s : s); if (rc) return rc;
+                          ss ? w.slab2_bytes : w.slab_bytes, nullptr, se); if (rc) return rc;
         }
         if (do1 && emb_nt) {   // dGgt^T, dGt^T and the transposed weight slices for the NT embedding gradient
             EmbPrepArgs ea{};
@@ -1353,32 +1394,33 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
                 ea.tile0[e] = tiles; tiles += ((ldds[e] + 31) / 32) * ((colss[e] + 31) / 32);
             }
             ea.tile0[3] = tiles;
-            hipLaunchKernelGGL(k_emb_prep, dim3(d.B + tiles), dim3(256), 0, s, ea);
+            hipLaunchKernelGGL(k_emb_prep, dim3(d.B + tiles), dim3(256), 0, se, ea);
             NCX_HIP_TRY(hipGetLastError());
         } else if (do1) {   // dGgt = one-hot(aid)^T dSh   (dGgt was cleared by k_bwd_prelude)
-            hipLaunchKernelGGL(k_scatter_dsh_by_answer, dim3(d.B), dim3(256), 0, s, (const float*)dsh, in->answer_aids, d.B, H, d.A, dagt);
+            hipLaunchKernelGGL(k_scatter_dsh_by_answer, dim3(d.B), dim3(256), 0, se, (const float*)dsh, in->answer_aids, d.B, H, d.A, dagt);
             NCX_HIP_TRY(hipGetLastError());
         }
         if (((do1 && !skip_de) || only_de) && bf16e) {
-            rc = prof_open(U_DE, s); if (rc) return rc;
-            rc = bf16_de(d, bm, dgt, g->answer_embedding, s); if (rc) return rc;
-            rc = prof_close(U_DE, s); if (rc) return rc;
+            rc = prof_open(U_DE, se); if (rc) return rc;
+            rc = bf16_de(d, bm, dgt, g->answer_embedding, se); if (rc) return rc;
+            rc = prof_close(U_DE, se); if (rc) return rc;
         } else if (((do1 && !skip_de) || only_de) && emb_nt) {   // dE = dGt^T . (W1ak^T)^T + dGgt^T . (W1agt^T)^T on the fused forward kernel
             MainArgs a{}; a.M = d.A; a.N = d.da; a.nseg = 2;
             a.seg[0].kind = MK_PLAIN; a.seg[0].a = dgtT;  a.seg[0].lda = Hp4; a.seg[0].klen = Hp4; a.seg[0].b = w1akT;  a.seg[0].ldb = Hp32;
             a.seg[1].kind = MK_PLAIN; a.seg[1].a = dagtT; a.seg[1].lda = Hp4; a.seg[1].klen = Hp4; a.seg[1].b = w1agtT; a.seg[1].ldb = Hp32;
             a.out = g->answer_embedding; a.ldo = d.da;
             a.split = 1;
-            rc = prof_open(U_DE, s); if (rc) return rc;
-            rc = main_forward(a, s); if (rc) return rc;
-            rc = prof_close(U_DE, s); if (rc) return rc;
+            rc = prof_open(U_DE, se); if (rc) return rc;
+            rc = main_forward(a, se); if (rc) return rc;
+            rc = prof_close(U_DE, se); if (rc) return rc;
         } else if ((do1 && !skip_de) || only_de) {   // dE[a][j] = sum_n dGt[n][a] W1ak[n][j] + sum_n dGgt[n][a] W1agt[n][j]
             GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 2; a.M = d.A;
             a.a[0] = x_plain(dgt, d.A, H, d.A);  a.b[0] = x_plain(p->w1 + o.a_other, din, H, d.da); a.klen[0] = H;
             a.a[1] = x_plain(dagt, d.A, H, d.A); a.b[1] = x_plain(p->w1 + o.a_gt, din, H, d.da);    a.klen[1] = H;
             a.out[0] = g->answer_embedding; a.ldo[0] = d.da; a.n_cols[0] = d.da;
-            rc = run_gemm(U_DE, a, FORM_TN, u[U_DE].plan, slab, w.slab_bytes, nullptr, s); if (rc) return rc;
+            rc = run_gemm(U_DE, a, FORM_TN, u[U_DE].plan, ss ? (float*)(ws + w.slab2) : slab, ss ? w.slab2_bytes : w.slab_bytes, nullptr, se); if (rc) return rc;
         }
+        if (km_deferred) { rc = run_km(); if (rc) return rc; }
         if (ss) { rc = side_join(ss, s); if (rc) return rc; }
     } else if (do1) {
         NCX_HIP_TRY(hipMemsetAsync(g->answer_embedding, 0, (size_t)d.A * d.da * 4, s));

@@ -12,24 +12,31 @@
 // S chunks (chunk z on XCD z: its dpre rows stay in that L2), partial tiles to a slab, fixed-order reduction afterwards.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
 #include "ncx_internal.h"
 
 namespace ncx {
 
-constexpr int KM_BM = 128, KM_BN = 64, KM_PA = KM_BM + 16, KM_PB = KM_BN + 16;   // LDS pitches = 16 mod 32: ds_read_b32 at its 2-cycle floor
+constexpr int KM_BN = 64, KM_PB = KM_BN + 16;   // LDS pitches = 16 mod 32: ds_read_b32 at its 2-cycle floor
 
 // K = rows per reduction step (a whole triplet, or a 24-row part of one: the rows of a step share v_o); Kc = candidates
 // per triplet, a multiple of K.
-template <int K>
-__global__ __launch_bounds__(256, 2) void k_dw_km(const float* __restrict__ dpre, int H, const float* __restrict__ feats, int dv,
+// EDGE: some tile of the launch reaches beyond H or dv (16-byte windows slid left and repaired); interior launches compile
+// the repair out -- the reduction step is then ONE basic block (a branch in it costs ~15 %: ncx_main.h).
+template <int K, int KM_BM, int OCC, bool EDGE, int ABL = 0>
+__global__ __launch_bounds__(256, OCC) void k_dw_km(const float* __restrict__ dpre, int H, const float* __restrict__ feats, int dv,
                                                   const int* __restrict__ idx_k, const int* __restrict__ idx_o, int B, int Kc,
                                                   int chunk, int tiles_m, int S, float* __restrict__ slab) {
     extern __shared__ __attribute__((aligned(16))) float km_smem[];
-    constexpr int a_elems = K * KM_PA, b_elems = K * KM_PB;
-    float* const lds_a = km_smem;                       // [2][K][KM_PA]
-    float* const lds_b = km_smem + 2 * a_elems;         // [2][K][KM_PB]
+    constexpr int KM_PA = KM_BM + 16, QA = KM_BM / 4;   // (QA: 16-byte quads per A row)
+    constexpr int NA = (K * QA + 255) / 256, NB = (K * 16 + 255) / 256;
+    constexpr int KA = NA * 256 / QA, KB = NB * 16;     // tile rows incl. the ones only the unconditional stores touch
+    constexpr int a_elems = KA * KM_PA, b_elems = KB * KM_PB;
+    float* const lds_a = km_smem;                       // [2][KA][KM_PA]
+    float* const lds_b = km_smem + 2 * a_elems;         // [2][KB][KM_PB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 32;
+    const int wm0 = (wave >> 1) * (KM_BM / 2), wn0 = (wave & 1) * 32;
     const int z = blockIdx.x % S, t = blockIdx.x / S;
     const int tm = t % tiles_m, tn = t / tiles_m;
     const int m0 = tm * KM_BM, n0 = tn * KM_BN;
@@ -38,7 +45,7 @@ __global__ __launch_bounds__(256, 2) void k_dw_km(const float* __restrict__ dpre
     if (t0 >= B) return;
     const int b0 = t0 * spt, b1 = t1 * spt;              // reduction steps of this chunk (step s: rows s*K .. s*K+K-1)
 
-    constexpr int WM = 4, WN = 2;
+    constexpr int WM = KM_BM / 32, WN = 2;
     f32x4 acc_k[WM][WN], acc_m[WM][WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i)
@@ -50,45 +57,63 @@ __global__ __launch_bounds__(256, 2) void k_dw_km(const float* __restrict__ dpre
     // Two register sets: the loads of triplet b+2 are issued before the MFMAs of triplet b, so every load has two
     // reduction steps to land; every load / LDS store is unconditional (triplet index clamped, a surplus step is folded
     // with weight 0): a branch around the loads makes the compiler drain vmcnt first.
-    constexpr int NA = (K * 32 + 255) / 256, NB = (K * 16 + 255) / 256;
-    const bool edge_a = m0 + KM_BM > H, edge_b = n0 + KM_BN > dv;       // (uniform per workgroup)
     f32x4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
-    float vo0[WN], vo1[WN];
-    auto issue = [&](f32x4 (&ra)[NA], f32x4 (&rb)[NB], float (&vo)[WN], int b) __attribute__((always_inline)) {
+    // Gather indices travel one more step ahead than the rows they name (set `ix` for triplet b+4 is requested while the rows
+    // of triplet b+2 are): an index fetched inside issue() put a full memory round trip in front of that step's row loads.
+    // The B tile's spare rows (K .. KB-1) carry the triplet's v_o slice: row K is what the fold multiplies by, so v_o needs
+    // no registers of its own (a register copy of it per step made the loop wait for loads it had just issued).
+    static_assert(KB > K, "the B tile needs a spare row for v_o");
+    struct Ix { int k[NB]; };
+    auto issue_idx = [&](Ix& ix, int b) __attribute__((always_inline)) {
+        b = min(b, b1 - 1);
+        const long long r0 = (long long)b * K;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int row = (tid + 256 * i) >> 4;
+            ix.k[i] = *(row < K ? idx_k + r0 + row : idx_o + r0);         // (idx_o is per row: any row of the step names its triplet's v_o)
+        }
+    };
+    auto issue = [&](f32x4 (&ra)[NA], f32x4 (&rb)[NB], const Ix& ix, int b) __attribute__((always_inline)) {
         const float keep = b < b1 ? 1.f : 0.f;
         b = min(b, b1 - 1);
         const long long r0 = (long long)b * K;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int f = tid + 256 * i, row = min(f >> 5, K - 1), c = m0 + 4 * (f & 31);
-            ra[i] = load_window(dpre + (r0 + row) * H, c, H);            // unconditional 16-byte window (repaired in stash on edge tiles)
+            const int f = tid + 256 * i, row = min(f / QA, K - 1), c = m0 + 4 * (f % QA);
+            ra[i] = EDGE ? load_window(dpre + (r0 + row) * H, c, H) : *(const f32x4u*)(dpre + (r0 + row) * H + c);   // (window repaired in stash)
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int f = tid + 256 * i, row = min(f >> 4, K - 1), c = n0 + 4 * (f & 15);
-            rb[i] = load_window(feats + (long long)idx_k[r0 + row] * dv, c, dv);
+            const int f = tid + 256 * i, c = n0 + 4 * (f & 15);
+            rb[i] = EDGE ? load_window(feats + (long long)ix.k[i] * dv, c, dv) : *(const f32x4u*)(feats + (long long)ix.k[i] * dv + c);
         }
-        const float* vor = feats + (long long)idx_o[r0] * dv;              // (idx_o is per row: any row of the step names its triplet's v_o)
-#pragma unroll
-        for (int j = 0; j < WN; ++j) vo[j] = vor[min(n0 + wn0 + 16 * j + li, dv - 1)];
         return keep;
     };
     auto stash = [&](const f32x4 (&ra)[NA], const f32x4 (&rb)[NB], int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int f = tid + 256 * i;
-            const f32x4 v = edge_a ? fix_window(ra[i], m0 + 4 * (f & 31), H) : ra[i];
-            if ((f >> 5) < K) *(f32x4*)(lds_a + buf * a_elems + (f >> 5) * KM_PA + 4 * (f & 31)) = v;
+            const f32x4 v = EDGE ? fix_window(ra[i], m0 + 4 * (f % QA), H) : ra[i];
+            *(f32x4*)(lds_a + buf * a_elems + (f / QA) * KM_PA + 4 * (f % QA)) = v;      // (rows >= K: copies of row K-1, never read)
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int f = tid + 256 * i;
-            const f32x4 v = edge_b ? fix_window(rb[i], n0 + 4 * (f & 15), dv) : rb[i];
-            if ((f >> 4) < K) *(f32x4*)(lds_b + buf * b_elems + (f >> 4) * KM_PB + 4 * (f & 15)) = v;
+            const f32x4 v = EDGE ? fix_window(rb[i], n0 + 4 * (f & 15), dv) : rb[i];
+            *(f32x4*)(lds_b + buf * b_elems + (f >> 4) * KM_PB + 4 * (f & 15)) = v;
         }
     };
     constexpr int nk4 = K / 4;
-    auto compute_fold = [&](int buf, const float (&vo)[WN], float keep) __attribute__((always_inline)) {
+    // One reduction step = one triplet.  The operand fragments of sub-step s4+2 are read from LDS under the MFMAs of sub-step
+    // s4 (read just before use, each group of 4 MFMAs waited ~100 cycles for its ds_read: the pipes ran at 64 %), and the first
+    // two sub-steps also carry the address arithmetic and global loads of the triplet two steps ahead.
+    auto read_frag = [&](const float* pa, const float* pb, int s4, float (&af)[WM], float (&bf)[WN]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) af[i] = pa[s4 * 4 * KM_PA + 16 * i];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bf[j] = pb[s4 * 4 * KM_PB + 16 * j];
+    };
+    auto step = [&](f32x4 (&ra)[NA], f32x4 (&rb)[NB], Ix& ix, int bnext, int buf, float keep) __attribute__((always_inline)) -> float {
         const float* pa = lds_a + buf * a_elems + lk * KM_PA + wm0 + li;
         const float* pb = lds_b + buf * b_elems + lk * KM_PB + wn0 + li;
         f32x4 tt[WM][WN];
@@ -96,56 +121,62 @@ __global__ __launch_bounds__(256, 2) void k_dw_km(const float* __restrict__ dpre
         for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < WN; ++j) tt[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float af[nk4][WM], bf[nk4][WN], vm[WN];
+        read_frag(pa, pb, 0, af[0], bf[0]);
+        read_frag(pa, pb, 1, af[1], bf[1]);
 #pragma unroll
-        for (int s4 = 0; s4 < nk4; ++s4) {
-            float af[WM], bf[WN];
+        for (int j = 0; j < WN; ++j) vm[j] = lds_b[buf * b_elems + K * KM_PB + wn0 + 16 * j + li];
+        __builtin_amdgcn_sched_barrier(0);
+        float knext = 0.f;
 #pragma unroll
-            for (int i = 0; i < WM; ++i) af[i] = pa[s4 * 4 * KM_PA + 16 * i];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) bf[j] = pb[s4 * 4 * KM_PB + 16 * j];
+        for (int s4 = 0; s4 < nk4; ++s4) {               // (one scheduling region per sub-step: reads cannot sink to their use)
+            if (s4 + 2 < nk4) read_frag(pa, pb, s4 + 2, af[s4 + 2], bf[s4 + 2]);
+            if (s4 == 0 && ABL != 2) knext = issue(ra, rb, ix, bnext);
+            if (s4 == 1 && ABL != 2) issue_idx(ix, bnext + 2);
+            if (ABL == 2) knext = 1.f;
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) tt[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bf[j], tt[i][j], 0, 0, 0);
+                for (int j = 0; j < WN; ++j) tt[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s4][i], bf[s4][j], tt[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        float vm[WN];
 #pragma unroll
-        for (int j = 0; j < WN; ++j) vm[j] = vo[j] * keep;
+        for (int j = 0; j < WN; ++j) vm[j] *= keep;
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < WN; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
+                    if (ABL == 4) { acc_k[i][j][q] += tt[i][j][q]; continue; }
                     acc_k[i][j][q] = __builtin_fmaf(tt[i][j][q], keep, acc_k[i][j][q]);
                     acc_m[i][j][q] = __builtin_fmaf(tt[i][j][q], vm[j], acc_m[i][j][q]);
                 }
+        return knext;
     };
 
-    float k0 = issue(ra0, rb0, vo0, b0);
-    float k1 = issue(ra1, rb1, vo1, b0 + 1);
+    Ix ix0, ix1;
+    issue_idx(ix0, b0); issue_idx(ix1, b0 + 1);
+    float k0 = issue(ra0, rb0, ix0, b0);
+    issue_idx(ix0, b0 + 2);
+    float k1 = issue(ra1, rb1, ix1, b0 + 1);
+    issue_idx(ix1, b0 + 3);
     stash(ra0, rb0, 0);
-    float vc[WN], kc = k0;                               // v_o and weight of the triplet whose tile sits in LDS[0]
-#pragma unroll
-    for (int j = 0; j < WN; ++j) vc[j] = vo0[j];
+    float kc = k0;                                       // weight of the triplet whose tile sits in LDS[0]
     __syncthreads();
     for (int b = b0; b < b1; b += 2) {
-        // LDS[0] = triplet b (vc, kc); set 1 = triplet b+1 in flight
-        k0 = issue(ra0, rb0, vo0, b + 2);
-        compute_fold(0, vc, kc);
-        stash(ra1, rb1, 1);
-        float vn[WN]; float kn = k1;
-#pragma unroll
-        for (int j = 0; j < WN; ++j) vn[j] = vo1[j];
-        __syncthreads();
-        // LDS[1] = triplet b+1 (vn, kn); set 0 = triplet b+2 in flight
-        k1 = issue(ra1, rb1, vo1, b + 3);
-        compute_fold(1, vn, kn);
-        stash(ra0, rb0, 0);
+        // LDS[0] = triplet b (kc); set 1 = triplet b+1 in flight; ix0 / ix1 = indices of triplets b+2 / b+3
+        k0 = step(ra0, rb0, ix0, b + 2, 0, kc);
+        __builtin_amdgcn_sched_barrier(0);               // (the compiler otherwise hoists the stash -- and its wait for ALL loads -- above the issue)
+        if (ABL != 3) stash(ra1, rb1, 1);
+        const float kn = k1;
+        if (ABL != 1) __syncthreads();
+        // LDS[1] = triplet b+1 (kn); set 0 = triplet b+2 in flight
+        k1 = step(ra1, rb1, ix1, b + 3, 1, kn);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ABL != 3) stash(ra0, rb0, 0);
         kc = k0;
-#pragma unroll
-        for (int j = 0; j < WN; ++j) vc[j] = vo0[j];
-        __syncthreads();
+        if (ABL != 1) __syncthreads();
     }
     float* dk = slab + ((long long)z * 2 + 0) * H * dv;
     float* dm = slab + ((long long)z * 2 + 1) * H * dv;
@@ -190,14 +221,43 @@ int dw_km(const ncx_dims& d, const float* dpre, const float* feats, const int* i
     // up to 8 k-chunks (one per XCD), at least 16 triplets each: tiny batches are not worth 8 partial tiles
     const int S = d.B / 16 >= DW_KM_SPLIT ? DW_KM_SPLIT : (d.B / 16 >= 1 ? d.B / 16 : 1);
     const int chunk = (d.B + S - 1) / S, nz = (d.B + chunk - 1) / chunk;
-    const int tiles_m = (d.H + KM_BM - 1) / KM_BM, tiles_n = (d.dv + KM_BN - 1) / KM_BN;
     constexpr int R = 24;
-    const int lds = 2 * R * (KM_PA + KM_PB) * 4;
-    static bool attr = false;
-    if (!attr) { NCX_HIP_TRY(hipFuncSetAttribute((const void*)k_dw_km<R>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = true; }
-    hipLaunchKernelGGL(k_dw_km<R>, dim3(tiles_m * tiles_n * S), dim3(256), lds, s, dpre, d.H, feats, d.dv, idx_k, idx_o, d.B, d.K, chunk,
-                       tiles_m, S, slab);
-    NCX_HIP_TRY(hipGetLastError());
+    // 128-row tiles at two workgroups per CU, or 64-row tiles at four (hook NCX_KM_BM=64)
+    int bm = 128;
+    if (const char* e = hook_env("NCX_KM_BM")) bm = atoi(e) == 64 ? 64 : 128;
+    const int tiles_m = (d.H + bm - 1) / bm, tiles_n = (d.dv + KM_BN - 1) / KM_BN;
+    const bool edge = d.H % bm != 0 || d.dv % KM_BN != 0;
+    auto go = [&](auto bm_c, auto occ_c, auto edge_c) -> int {
+        constexpr int BM = decltype(bm_c)::value, OCC = decltype(occ_c)::value;
+        constexpr bool EDGE = decltype(edge_c)::value;
+        constexpr int QA = BM / 4, NA = (R * QA + 255) / 256, KA = NA * 256 / QA, KB = (R * 16 + 255) / 256 * 16;
+        const int lds = 2 * (KA * (BM + 16) + KB * KM_PB) * 4;
+        static bool attr = false;
+        if (!attr) { NCX_HIP_TRY(hipFuncSetAttribute((const void*)k_dw_km<R, BM, OCC, EDGE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = true; }
+        hipLaunchKernelGGL((k_dw_km<R, BM, OCC, EDGE>), dim3(tiles_m * tiles_n * S), dim3(256), lds, s, dpre, d.H, feats, d.dv, idx_k, idx_o, d.B, d.K,
+                           chunk, tiles_m, S, slab);
+        return (int)hipGetLastError();
+    };
+    typedef std::integral_constant<int, 128> B128; typedef std::integral_constant<int, 64> B64;
+    typedef std::integral_constant<int, 2> O2; typedef std::integral_constant<int, 4> O4;
+    int rc;
+    int abl = 0;
+    if (const char* e = hook_env("NCX_KM_ABL")) abl = atoi(e);
+    if (abl >= 1 && abl <= 4 && !edge && bm == 128) {        // timing ablations (results are wrong): 1 no barrier, 2 no global loads, 3 no LDS stores, 4 no fold
+        const int lds = 2 * (24 * (128 + 16) + 32 * KM_PB) * 4;
+        auto run = [&](auto abl_c) -> int {
+            constexpr int A = decltype(abl_c)::value;
+            NCX_HIP_TRY(hipFuncSetAttribute((const void*)k_dw_km<R, 128, 2, false, A>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            hipLaunchKernelGGL((k_dw_km<R, 128, 2, false, A>), dim3(tiles_m * tiles_n * S), dim3(256), lds, s, dpre, d.H, feats, d.dv, idx_k, idx_o, d.B, d.K,
+                               chunk, tiles_m, S, slab);
+            return (int)hipGetLastError();
+        };
+        rc = abl == 1 ? run(std::integral_constant<int, 1>{}) : abl == 2 ? run(std::integral_constant<int, 2>{})
+           : abl == 3 ? run(std::integral_constant<int, 3>{}) : run(std::integral_constant<int, 4>{});
+    } else
+    if (bm == 128) rc = edge ? go(B128{}, O2{}, std::true_type{}) : go(B128{}, O2{}, std::false_type{});
+    else           rc = edge ? go(B64{}, O4{}, std::true_type{}) : go(B64{}, O4{}, std::false_type{});
+    if (rc) return rc;
     const long long n = (long long)d.H * d.dv;
     hipLaunchKernelGGL(k_dw_km_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)slab, nz, d.H, d.dv, din, g_vother,
                        g_vmult);

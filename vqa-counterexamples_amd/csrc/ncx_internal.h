@@ -69,6 +69,7 @@ struct WsLayout {
     size_t total;
 };
 constexpr int NCX_COLSUM_CHUNKS = 256;
+constexpr int NCX_PRELUDE_WAVES = 1024;       // waves of k_bwd_prelude = rows of its partial sums (>= NCX_COLSUM_CHUNKS: same buffer)
 
 // ncx_main.hip: the fused forward kernel of the Linear layers (segments of never-materialised operands chained into one
 // accumulator; Sh / bias / ReLU / Dropout in the epilogue)
