@@ -193,18 +193,31 @@ __global__ __launch_bounds__(256, OCC) void k_dw_km(const float* __restrict__ dp
         }
 }
 
+// Fixed-order sum of the k-chunk partials.  VEC: 4 consecutive columns per thread (dv % 4 == 0); all chunk loads are issued
+// before the first add (DW_KM_SPLIT is a compile-time bound: a runtime-length loop made every chunk a dependent round trip).
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_dw_km_reduce(const float* __restrict__ slab, int nz, int H, int dv, long long din,
                                                       float* __restrict__ g_vother, float* __restrict__ g_vmult) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)H * dv) return;
+    constexpr int W = VEC ? 4 : 1;
+    typedef float vec __attribute__((ext_vector_type(VEC ? 4 : 1)));
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * W, n = (long long)H * dv;
+    if (i >= n) return;
     const int h = (int)(i / dv), c = (int)(i - (long long)h * dv);
-    float sk = 0.f, sm = 0.f;
-    for (int z = 0; z < nz; ++z) {
-        sk += slab[((long long)z * 2 + 0) * H * dv + i];
-        sm += slab[((long long)z * 2 + 1) * H * dv + i];
+    vec vk[DW_KM_SPLIT], vm[DW_KM_SPLIT];
+#pragma unroll
+    for (int z = 0; z < DW_KM_SPLIT; ++z) {
+        const int zz = z < nz ? z : nz - 1;
+        vk[z] = *(const vec*)(slab + ((long long)zz * 2 + 0) * n + i);
+        vm[z] = *(const vec*)(slab + ((long long)zz * 2 + 1) * n + i);
     }
-    g_vother[(long long)h * din + c] = sk;
-    g_vmult[(long long)h * din + c] = sm;
+    vec sk = vk[0], sm = vm[0];
+#pragma unroll
+    for (int z = 1; z < DW_KM_SPLIT; ++z) { const vec zero = {}; sk += z < nz ? vk[z] : zero; sm += z < nz ? vm[z] : zero; }
+#pragma unroll
+    for (int j = 0; j < W; ++j) {                        // (rows of linear_1.weight are din floats apart: not 16-byte aligned in general)
+        g_vother[(long long)h * din + c + j] = sk[j];
+        g_vmult[(long long)h * din + c + j] = sm[j];
+    }
 }
 
 bool dw_km_supported(const ncx_dims& d) {
@@ -259,8 +272,9 @@ int dw_km(const ncx_dims& d, const float* dpre, const float* feats, const int* i
     else           rc = edge ? go(B64{}, O4{}, std::true_type{}) : go(B64{}, O4{}, std::false_type{});
     if (rc) return rc;
     const long long n = (long long)d.H * d.dv;
-    hipLaunchKernelGGL(k_dw_km_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)slab, nz, d.H, d.dv, din, g_vother,
-                       g_vmult);
+    const bool vec = d.dv % 4 == 0 && ((uintptr_t)slab & 15) == 0;      // 16-byte loads of the partials
+    if (vec) hipLaunchKernelGGL(k_dw_km_reduce<true>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, (const float*)slab, nz, d.H, d.dv, din, g_vother, g_vmult);
+    else     hipLaunchKernelGGL(k_dw_km_reduce<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)slab, nz, d.H, d.dv, din, g_vother, g_vmult);
     NCX_HIP_TRY(hipGetLastError());
     return NCX_OK;
 }

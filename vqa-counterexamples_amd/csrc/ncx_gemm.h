@@ -932,8 +932,16 @@ __global__ __launch_bounds__(256) void split_fixup_kernel(const FixupArgs a) {
     const int e = blockIdx.y * 1024 + threadIdx.x * 4;
     f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
     const WgMap wmap{(a.M + BM - 1) / BM, tiles_n, S};
-    for (int z = 0; z < S; ++z)                        // k-chunk order: deterministic
-        acc4 += *(const f32x4*)(a.slab + ((long long)a.wg0[prob] + wmap.encode(tile / tiles_n, tile % tiles_n, z)) * (BM * BN) + e);
+    // k-chunk order: deterministic.  Eight partial tiles are requested before the first is added (one load per iteration of a
+    // runtime-length loop is one dependent round trip per k-chunk: 7 / 14 us for 4-16 chunks)
+    for (int z = 0; z < S; z += 8) {
+        f32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            v[j] = *(const f32x4*)(a.slab + ((long long)a.wg0[prob] + wmap.encode(tile / tiles_n, tile % tiles_n, min(z + j, S - 1))) * (BM * BN) + e);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc4 += z + j < S ? v[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const int gr = m0 + e / BN, c = e % BN;
     if (gr < a.M) {
 #pragma unroll
