@@ -96,6 +96,18 @@ def cpu_baseline(steps=50, warmup=10, one_thread_steps=12, heldout=None):
     return out
 
 
+def workload_label(args, c):
+    """Which BASELINE.json config the flags select (the default flags are configs[1], the headline)."""
+    if args.c3:
+        return "configs[2]: fused HIP MUTAN producer (vqa_forward) + "
+    if (args.batch, c["K"], c["H"], c["L"]) == (512, 24, 256, 1):
+        return "configs[1] shape, bf16-operand variant (NOT the headline): " if args.bf16 else "configs[1]: "
+    if (args.batch, c["K"]) == (1024, 48):
+        return ("configs[4] shape (48 candidates, batch 1024, bf16 operands), one GPU: " if args.bf16
+                else "configs[4] shape (48 candidates, batch 1024) in fp32, one GPU: ")
+    return "non-BASELINE shape (--batch/--K/--H/--L given): "
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -266,10 +278,11 @@ def main():
                    warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True,
                    scaling=args.scaling, vs_baseline=None, dtype="bf16 operands / f32 accumulate (first-layer GEMMs), f32 elsewhere" if args.bf16 else "f32",
                    data="synthetic",
-                   config=dict(workload=("configs[2]: fused HIP MUTAN producer (vqa_forward) + " if args.c3 else "configs[1]: ") +
+                   config=dict(workload=workload_label(args, c) +
                                         "NeuralCX MLP train step (fwd+listwise loss/recall+bwd+Adam), synthetic "
-                                        "2048-d feats, %d candidates, batch %d per GPU (%s scaling: global batch %d), H=%d, L=%d, dropout 0.25, fp32"
-                                        % (c["K"], args.batch, args.scaling, gb, c["H"], c["L"]),
+                                        "2048-d feats, %d candidates, batch %d per GPU (%s scaling: global batch %d), H=%d, L=%d, dropout 0.25, %s"
+                                        % (c["K"], args.batch, args.scaling, gb, c["H"], c["L"],
+                                           "bf16 operands / fp32 accumulate for the linear_1 and answer-embedding products, fp32 elsewhere" if args.bf16 else "fp32"),
                                global_batch=gb, candidates=c["K"], dim_h=c["H"], n_layers=c["L"],
                                parallelism="dp%d" % world, feature_table_rows=args.n_img, final_loss=round(loss, 5)),
                    roofline=roof)

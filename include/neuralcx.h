@@ -152,7 +152,11 @@ int ncx_backward(const ncx_dims* d, const ncx_inputs* in, const ncx_params* p,
  *                 ncx_ws_region(NCX_WS_DGT);  4 = answer_embedding gradient = dGt^T . W1ak + dGgt^T . W1agt.
  *                 The embedding gradient is linear in that region, so a DP job sums the 4 MB region over ranks
  *                 between 3 and 4 instead of all-reducing the 19 MB [A, da] gradient (every rank then computes the
- *                 same, complete gradient). */
+ *                 same, complete gradient).
+ *   phase 5 | 2 | 4:  5 = phase 1 without the answer_embedding product: out.*, linear_2/3.*, linear_1.bias, and the
+ *                 region dGt | dGgt complete (as after phase 3) -- a DP job starts summing the region here, runs
+ *                 phase 2 (linear_1.weight: most of the backward) under that exchange, starts the exchange of the
+ *                 remaining gradients, and runs phase 4 under it. */
 int ncx_backward_phase(const ncx_dims* d, const ncx_inputs* in, const ncx_params* p,
                        void* workspace, size_t workspace_bytes, const float* dscores,
                        const ncx_grads* g, int32_t phase, void* stream);

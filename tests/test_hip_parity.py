@@ -401,3 +401,13 @@ def test_phased_backward_is_bit_identical():
         blk.mul_(2.0)
         ops.backward(dims, b, p, ws, lr["dscores"], g34, phase=4)
         assert torch.equal(2.0 * g0["answer_embedding"], g34["answer_embedding"])
+        # the three-way cut the DP engine uses (5 | 2 | 4): the block first, then linear_1.weight, then the embedding gradient
+        g524 = {k: torch.full_like(v, float("nan")) for k, v in p.items()}
+        ops.backward(dims, b, p, ws, lr["dscores"], g524, phase=5)
+        assert torch.isnan(g524["answer_embedding"]).all() and torch.isnan(g524["w1"]).all()
+        blk5 = ops.ws_dgt_view(dims, ws).clone()
+        ops.backward(dims, b, p, ws, lr["dscores"], g524, phase=2)
+        assert torch.equal(blk5, ops.ws_dgt_view(dims, ws))          # phase 2 leaves the exchanged block alone
+        ops.backward(dims, b, p, ws, lr["dscores"], g524, phase=4)
+        for k in g0:
+            assert torch.equal(g0[k], g524[k]), k

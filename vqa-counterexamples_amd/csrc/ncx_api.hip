@@ -1200,13 +1200,15 @@ int ncx_backward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, 
 
 int ncx_backward_phase(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, void* workspace,
                        size_t workspace_bytes, const float* dscores, const ncx_grads* g, int32_t phase, void* stream_) {
-    if (phase < 0 || phase > 4) return NCX_E_FLAGS;
+    if (phase < 0 || phase > 5) return NCX_E_FLAGS;
     return backward_impl(dp, in, p, workspace, workspace_bytes, dscores, g, stream_, phase);
 }
 
 // phase 0: everything.  phase 1: out / hidden layers / b1 and the answer_embedding gradient (complete when it
 // returns);  phase 2: linear_1.weight.  1 then 2 == 0 bit for bit (same kernels, the dGt problem launched alone).
 // phase 3: everything except the answer_embedding GEMM (leaves dGt | dGgt in the workspace, ncx_ws_region);
+// phase 5: phase 1 without the answer_embedding GEMM (leaves dGt | dGgt like phase 3): 5, 2, 4 == 0 bit for bit, and the
+// region can be on the wire while phase 2 (the bulk of the backward) runs.
 // phase 4: answer_embedding gradient from dGt | dGgt.  3 then 4 == 0 bit for bit; under data parallelism the
 // 2 x [H, A] block is summed over ranks between the two, so the [A, da] embedding gradient never crosses the wire.
 static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, void* workspace,
@@ -1254,8 +1256,8 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
     const float* hL = (const float*)(ws + w.h[d.L - 1]);
     float* dpre = (float*)(ws + w.dpre[0]);
     const bool only_de = phase == 4;                    // phase 4: just the dE GEMM
-    const bool skip_de = phase == 3;
-    const bool do1 = phase != 2 && !only_de, do2 = phase != 1 && !only_de;
+    const bool skip_de = phase == 3 || phase == 5;
+    const bool do1 = phase != 2 && !only_de, do2 = phase != 1 && phase != 5 && !only_de;
     if (!do1) {                                       // phase 2: dpre_1 lives where phase 1 left it
         dpre = (float*)(ws + w.dpre[(d.L - 1) & 1]);
     } else {

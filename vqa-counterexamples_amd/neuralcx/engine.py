@@ -158,13 +158,16 @@ class NeuralCXEngine:
         if self.world_size > 1:
             # The embedding gradient dE = dGt^T.W1ak + dGgt^T.W1agt is linear in the 2 x [H, A] block dGt | dGgt: the
             # ranks sum THAT block (4 MB at H=256) and each computes the complete dE itself, so the 19 MB [A, da]
-            # gradient never crosses xGMI.  Bucket 2 (linear_1.weight .. out.bias, 14.4 MB) is on the wire while the dE
-            # GEMM runs; only answer_embedding is excluded from it (it is first in the flat buffer).
+            # gradient never crosses xGMI.  Order (ncx_backward_phase 5 | 2 | 4): the block is produced FIRST and is on
+            # the wire while the bulk of the backward (linear_1.weight: ~0.35 ms at configs[1]) runs; bucket 2
+            # (linear_1.weight .. out.bias, 14.4 MB; only answer_embedding, first in the flat buffer, is excluded) is on
+            # the wire while the dE GEMM and answer_embedding's Adam slice run.
             n_emb = self.params.offsets["linear_1.weight"]
             f = self.params.fields()
-            ops.backward(d, batch, f, self._ws, r["dscores"], self.grads.fields(), phase=3)
             if self.flags & NCX_F_A_EMB:
+                ops.backward(d, batch, f, self._ws, r["dscores"], self.grads.fields(), phase=5)
                 h1 = torch.distributed.all_reduce(ops.ws_dgt_view(d, self._ws), group=self.pg, async_op=True)
+                ops.backward(d, batch, f, self._ws, r["dscores"], self.grads.fields(), phase=2)
                 h2 = torch.distributed.all_reduce(self.grads.flat[n_emb:], group=self.pg, async_op=True)
                 h1.wait()
                 ops.backward(d, batch, f, self._ws, r["dscores"], self.grads.fields(), phase=4)
@@ -177,7 +180,7 @@ class NeuralCXEngine:
                 r["scores"] = scores
                 return r
             else:                                   # a_emb lesion: the embedding gradient is zero everywhere
-                ops.backward(d, batch, f, self._ws, r["dscores"], self.grads.fields(), phase=4)
+                ops.backward(d, batch, f, self._ws, r["dscores"], self.grads.fields())
                 torch.distributed.all_reduce(self.grads.flat[n_emb:], group=self.pg)
         else:
             ops.backward(d, batch, self.params.fields(), self._ws, r["dscores"], self.grads.fields())

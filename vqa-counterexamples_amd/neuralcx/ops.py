@@ -149,7 +149,7 @@ def forward(d: NcxDims, batch: Batch, params: Dict[str, torch.Tensor], ws: torch
 
 def backward(d: NcxDims, batch: Batch, params: Dict[str, torch.Tensor], ws: torch.Tensor, dscores: torch.Tensor,
              grads: Dict[str, torch.Tensor], phase: int = 0) -> None:
-    """phase 0: whole backward.  phases 1 | 2 and 3 | 4: the two ways to halve it for comm overlap (ncx_backward_phase)."""
+    """phase 0: whole backward.  phases 1 | 2, 3 | 4 and 5 | 2 | 4: the ways to cut it for comm overlap (ncx_backward_phase)."""
     p, n = _ws_ptr(ws)
     ins, ps, gs = batch.c_struct(), _params_struct(params, NcxParams), _params_struct(grads, NcxGrads)
     if phase == 0:
