@@ -111,6 +111,8 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64) ? 4 : (BM * BN <= 64 * 12
     stash(ra0, rb0, 0);
     __syncthreads();
     for (int t = 0; t < nk; t += 2) {
+        // (order left to the compiler: pinned as issue | compute | stash -- loads two K-steps ahead, all LDS stores at the end of the
+        // step -- this kernel ran 296 us instead of 263 at the configs[4] shape: the stores must spread under the MFMAs)
         issue(ra0, rb0, min(t + 2, nk - 1));
         compute(0);
         stash(ra1, rb1, 1);
@@ -236,11 +238,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const u16* __restr
         issue_m(ra0, rb0, km0, t2 + 2);
         __builtin_amdgcn_sched_barrier(0);        // keeps the loads ahead of the MFMA block (measured: 198 -> 186 us; the NT kernel lost with it)
         compute(0);
+        __builtin_amdgcn_sched_barrier(0);
         stash_m(ra1, rb1, km1, 1);
         __syncthreads();
         issue_m(ra1, rb1, km1, t2 + 3);
         __builtin_amdgcn_sched_barrier(0);
         compute(1);
+        __builtin_amdgcn_sched_barrier(0);
         stash_m(ra0, rb0, km0, 0);
         __syncthreads();
     }
