@@ -223,6 +223,33 @@ def test_cli_synthetic_smoke(tmp_path, capsys):
     assert os.path.exists(os.path.join(runs, "val.jsonl"))            # scalars the reference sends to tensorboard
 
 
+def test_cli_configs3_scale_on_one_gpu(tmp_path, capsys):
+    """BASELINE configs[3] at its stated size on the hardware a test can have: ~440 k synthetic triplets (2048-d features over
+    a COCO-train-sized table of 82 783 rows, 24 candidates, global batch 512), one epoch through the CLI on ONE GPU -- the
+    8-GPU partition of the same epoch is dp.epoch_plan's contiguous slices, covered by the gloo tests.  Every triplet is
+    consumed once, the planted ranking signal is learned (chance Recall@5 = 0.208), the last partial batch (440 000 = 859 x 512
+    + 192) is kept as the reference's batchify keeps it (counterexamples.py:509-516)."""
+    import re
+    import counterexamples as cli
+    n_train = 440000
+    cli.main(["--synthetic", "--path_opt", os.path.join(PKG, "options", "cx", "neuralcx_256_1_all.yaml"), "-b", "512",
+              "--epochs", "1", "--syn_train", str(n_train), "--syn_val", "4096", "--syn_images", "82783", "-p", "860",
+              "--project_dir", str(tmp_path)])
+    out = capsys.readouterr().out
+    m = re.search(r"Epoch 1 train: loss: ([0-9.]+), recall: ([0-9.]+), triplets/s: ([0-9.]+)", out)
+    assert m, out[-2000:]                                     # printed at step 860 = the partial last batch: all 440 000 seen
+    train_loss, train_r5, rate = float(m.group(1)), float(m.group(2)), float(m.group(3))
+    v = re.search(r"Epoch 1 val: loss: ([0-9.]+), recall: ([0-9.]+), recall_1: ([0-9.]+), recall_5: ([0-9.]+)", out)
+    assert v, out[-2000:]
+    val_loss, val_r5, val_r1 = float(v.group(1)), float(v.group(4)), float(v.group(3))
+    assert train_loss < np.log(24.0) - 0.2 and val_loss < np.log(24.0) - 0.2      # (chance loss = ln 24 = 3.178)
+    assert val_r5 > 0.45 and val_r1 > 0.10, (val_r1, val_r5)                      # chance: 0.208 / 0.042
+    assert rate > 1e5                                          # whole-epoch rate incl. batch synthesis (loose: boxes differ)
+    base = os.path.join(str(tmp_path), "logs", "cx")
+    info = torch.load(os.path.join(base, os.listdir(base)[0], "ckpt", "info.ckpt"))
+    assert abs(info[-1]["recall"] - val_r5) < 1e-3
+
+
 def test_cli_real_data_mode_on_reference_format_files(tmp_path, capsys):
     """the CLI's default (real-data) mode on files in the reference's on-disk formats -- pickles, feature
     tables, answer embedding -- kept resident on the device; the per-batch pipeline (index slices -> question encoder ->
