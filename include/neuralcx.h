@@ -36,6 +36,8 @@ extern "C" {
 #define NCX_E_DIMS       -2   /* a dimension is out of the supported range */
 #define NCX_E_WORKSPACE  -3   /* workspace too small / misaligned */
 #define NCX_E_FLAGS      -4   /* inconsistent flags / lesion inputs */
+#define NCX_E_UNSUPPORTED -5  /* the RCCL library could not be loaded (ncx_comm_* / ncx_allreduce only) */
+#define NCX_E_COMM       -6   /* RCCL reported an error */
 
 /* model_spec switches of the reference (vqa/models/cx.py:265-307), 1 = feature present */
 #define NCX_F_V_MULT   (1u << 0)   /* v_orig * v_other segment (cx.py:295-298), else zeros          */
@@ -166,6 +168,21 @@ int ncx_backward_phase(const ncx_dims* d, const ncx_inputs* in, const ncx_params
 #define NCX_WS_H1 2     /* diagnostics / tests: post-dropout activations of linear_1, [B*K, H] (valid after ncx_forward) */
 #define NCX_WS_DPRE1 3  /* diagnostics / tests: gradient of linear_1's pre-activations, [B*K, H] (valid after ncx_backward) */
 int ncx_ws_region(const ncx_dims* d, int32_t which, size_t* offset, size_t* bytes);
+
+/* Gradient exchange of a data-parallel job (net-new: the reference is single-GPU; /root/reference/counterexamples.py:334-339
+ * is where a DP job sums gradients between loss.backward() and optimizer.step()).  An opaque handle around one RCCL
+ * communicator -- the library's only other state; RCCL is loaded on first use (NCX_E_UNSUPPORTED when it is absent).
+ *   rank 0:      ncx_comm_unique_id(id)          -> 128 bytes the host hands to every rank (file, socket, MPI ...)
+ *   every rank:  hipSetDevice(local GPU); ncx_comm_create(id, nranks, rank, &comm)
+ *   per step:    ncx_allreduce(comm, buf, n, stream)   in-place fp32 SUM over ranks, ordered on `stream`
+ *                (the engine's two buckets: the dGt | dGgt workspace region and the flat gradient tail)
+ * The Python host uses torch.distributed's RCCL backend for the same collective. */
+#define NCX_COMM_ID_BYTES 128
+typedef struct ncx_comm ncx_comm;
+int ncx_comm_unique_id(void* id128);
+int ncx_comm_create(const void* id128, int32_t nranks, int32_t rank, ncx_comm** out);
+int ncx_comm_destroy(ncx_comm* comm);
+int ncx_allreduce(ncx_comm* comm, float* buf, size_t n, void* stream);
 
 /* Replaces torch.optim.Adam(...).step() (counterexamples.py:275-276,339) on a flat fp32 buffer:
  * defaults betas (0.9, 0.999), eps 1e-8, no weight decay, no amsgrad.  `step` is the 1-based step

@@ -37,6 +37,10 @@ def test_host_only_entry_points():
     # argument validation happens before any launch: NULL pointers are rejected without a GPU
     assert _lib.lib().ncx_loss_rank(None, None, 4, 24, 0.0, None, None, None, None, None, None) == -1
     assert _lib.lib().ncx_adam_step(None, None, None, None, 4, 1e-4, 0.9, 0.999, 1e-8, 1, 1.0, None) == -1
+    # the RCCL handle validates its arguments before it loads RCCL
+    assert _lib.lib().ncx_allreduce(None, None, 4, None) == -1 and _lib.lib().ncx_comm_unique_id(None) == -1
+    comm = ctypes.c_void_p()
+    assert _lib.lib().ncx_comm_create(ctypes.create_string_buffer(128), 2, 2, ctypes.byref(comm)) == -2     # rank >= nranks
 
 
 def test_struct_layout_matches_header():

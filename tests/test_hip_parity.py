@@ -411,3 +411,30 @@ def test_phased_backward_is_bit_identical():
         ops.backward(dims, b, p, ws, lr["dscores"], g524, phase=4)
         for k in g0:
             assert torch.equal(g0[k], g524[k]), k
+
+
+def test_c_abi_rccl_handle_allreduce_on_one_rank():
+    """ncx_comm_* / ncx_allreduce (include/neuralcx.h): RCCL is loaded, a communicator is created on this GPU and the fp32 sum
+    all-reduce runs on the caller's stream.  One rank is what a one-GPU box allows (RCCL refuses two ranks on one device): the
+    sum over one rank is the identity, and it must be ordered after the kernel that produced the buffer and before its reader."""
+    from neuralcx import _lib
+    torch.cuda.set_device(0)
+    uid = _lib.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = _lib.comm_create(uid, 1, 0)
+    try:
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            x = torch.randn(1 << 22, device=dev())                    # 16 MB: the size of the engine's second bucket
+            ref = x.clone()
+            y = x * 2.0                                              # producer on the same stream
+            _lib.allreduce(comm, y)
+            z = y + 1.0                                              # consumer on the same stream
+        side.synchronize()
+        assert torch.equal(y, ref * 2.0) and torch.equal(z, ref * 2.0 + 1.0)
+        _lib.allreduce(comm, torch.empty(0, device=dev()))            # n == 0: nothing enqueued
+        with pytest.raises(TypeError):
+            _lib.allreduce(comm, torch.zeros(4, dtype=torch.float64, device=dev()))
+    finally:
+        _lib.comm_destroy(comm)
+

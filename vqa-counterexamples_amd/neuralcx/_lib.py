@@ -17,7 +17,8 @@ NCX_F_BF16 = 16       # BASELINE configs[4]: bf16 operands for the two dominant 
 
 EXPORTS = ("ncx_input_size", "ncx_workspace_bytes", "ncx_forward", "ncx_loss_rank", "ncx_backward", "ncx_backward_phase",
            "ncx_adam_step", "ncx_version", "ncx_profile_begin", "ncx_profile_end", "ncx_plan_query",
-           "ncx_vqa_workspace_bytes", "ncx_vqa_forward", "ncx_knn_workspace_bytes", "ncx_knn", "ncx_ws_region", "ncx_wgmap_check")
+           "ncx_vqa_workspace_bytes", "ncx_vqa_forward", "ncx_knn_workspace_bytes", "ncx_knn", "ncx_ws_region", "ncx_wgmap_check",
+           "ncx_comm_unique_id", "ncx_comm_create", "ncx_comm_destroy", "ncx_allreduce")
 
 
 class NcxDims(C.Structure):
@@ -54,7 +55,8 @@ class NcxError(RuntimeError):
 
 
 _ERR = {-1: "NCX_E_NULL (required pointer is NULL)", -2: "NCX_E_DIMS (dimension out of range)",
-        -3: "NCX_E_WORKSPACE (workspace too small or misaligned)", -4: "NCX_E_FLAGS (inconsistent lesion inputs)"}
+        -3: "NCX_E_WORKSPACE (workspace too small or misaligned)", -4: "NCX_E_FLAGS (inconsistent lesion inputs)",
+        -5: "NCX_E_UNSUPPORTED (RCCL could not be loaded)", -6: "NCX_E_COMM (RCCL reported an error)"}
 
 _lib = None
 
@@ -109,6 +111,10 @@ def lib():
     L.ncx_profile_begin.argtypes = [C.c_uint32, C.c_int32]
     L.ncx_profile_end.restype = C.c_int
     L.ncx_profile_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int32]
+    L.ncx_comm_unique_id.restype = C.c_int; L.ncx_comm_unique_id.argtypes = [C.c_void_p]
+    L.ncx_comm_create.restype = C.c_int; L.ncx_comm_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.ncx_comm_destroy.restype = C.c_int; L.ncx_comm_destroy.argtypes = [C.c_void_p]
+    L.ncx_allreduce.restype = C.c_int; L.ncx_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     L.ncx_plan_query.restype = C.c_int
     L.ncx_plan_query.argtypes = [C.POINTER(NcxDims), C.c_int32, C.POINTER(C.c_int32)]
     _lib = L
@@ -156,3 +162,35 @@ def plan_query(d, name):
     check(lib().ncx_plan_query(C.byref(d), GEMM_IDS[name], out), "ncx_plan_query")
     return dict(form=("NT", "TN", "NN")[out[0]], M=out[1], N=out[2], ksteps=out[3],
                 tile=("64x64", "128x128", "96x128", "96x64", "128x64", "48x128", "48x64 (per-triplet fold of the two v segments)")[out[4]], ksplit=out[5])
+
+
+# ---- the C ABI's RCCL handle (include/neuralcx.h: ncx_comm_*, ncx_allreduce) ---------------------------------------------
+# The engine exchanges gradients through torch.distributed (backend "nccl" = RCCL); these wrappers are the same collective
+# for a host that binds the C ABI without torch.distributed, and what the GPU test drives.
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    check(lib().ncx_comm_unique_id(buf), "ncx_comm_unique_id")
+    return buf.raw
+
+
+def comm_create(unique_id: bytes, nranks: int, rank: int) -> C.c_void_p:
+    """Binds the CURRENT device (torch.cuda.set_device first).  Collective: every rank calls it with the same id."""
+    if len(unique_id) != 128:
+        raise ValueError("unique id must be the 128 bytes ncx_comm_unique_id produced on rank 0")
+    comm = C.c_void_p()
+    check(lib().ncx_comm_create(C.create_string_buffer(unique_id, 128), int(nranks), int(rank), C.byref(comm)), "ncx_comm_create")
+    return comm
+
+
+def allreduce(comm: C.c_void_p, t, stream_ptr=None) -> None:
+    """In-place fp32 sum over the ranks of `comm`, ordered on the given HIP stream (default: torch's current stream)."""
+    import torch
+    if t.dtype != torch.float32 or not t.is_contiguous() or not t.is_cuda:
+        raise TypeError("ncx_allreduce takes a contiguous fp32 device tensor")
+    sp = torch.cuda.current_stream(t.device).cuda_stream if stream_ptr is None else stream_ptr
+    check(lib().ncx_allreduce(comm, C.c_void_p(t.data_ptr()), t.numel(), C.c_void_p(sp)), "ncx_allreduce")
+
+
+def comm_destroy(comm: C.c_void_p) -> None:
+    check(lib().ncx_comm_destroy(comm), "ncx_comm_destroy")
+
