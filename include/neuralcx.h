@@ -56,6 +56,12 @@ extern "C" {
  * weights and skips that GEMM.  The caller owns the invariant (the engine sets it from the second batch of an
  * evaluation pass on). */
 #define NCX_F_REUSE_GT (1u << 5)
+/* Training steps (counterexamples.py:330-339: forward, criterion, backward back to back): with this bit the out layer
+ * (cx.py:327), the loss / Recall pass and the head of the backward run as ONE pass over the last hidden activations in
+ * ncx_train_tail -- ncx_forward then leaves `scores` alone (it may be NULL) and ncx_backward[_phase] expects ncx_train_tail to
+ * have run on the same workspace (its `dscores` may be NULL).  K <= 32 and H <= 256 only (ncx_train_tail says NCX_E_DIMS
+ * otherwise: clear the bit and use the three calls). */
+#define NCX_F_FUSED_TAIL (1u << 6)
 /* (v_emb / q_emb / z_emb lesions replace INPUTS by uniform noise: the host does that before the call) */
 
 typedef struct ncx_dims {
@@ -168,6 +174,16 @@ int ncx_backward_phase(const ncx_dims* d, const ncx_inputs* in, const ncx_params
 #define NCX_WS_H1 2     /* diagnostics / tests: post-dropout activations of linear_1, [B*K, H] (valid after ncx_forward) */
 #define NCX_WS_DPRE1 3  /* diagnostics / tests: gradient of linear_1's pre-activations, [B*K, H] (valid after ncx_backward) */
 int ncx_ws_region(const ncx_dims* d, int32_t which, size_t* offset, size_t* bytes);
+
+/* NCX_F_FUSED_TAIL: replaces, in one pass over h_L, the tail of ncx_forward (`out`, cx.py:327), ncx_loss_rank
+ * (counterexamples.py:310,334,501-506) and the head of ncx_backward (d out.weight, d out.bias, the gradient of the last
+ * pre-activations; for L == 1 also d linear_1.bias).  Call order: ncx_forward, ncx_train_tail, ncx_backward[_phase], all with the
+ * same dims (flag set) and workspace.  Outputs as ncx_loss_rank (scale = dims.loss_scale, 1/B when <= 0) plus `scores`
+ * [B, K]; dscores is optional.  Bit-identical to the three separate calls except d out.bias (zero in maths; its partial sums
+ * are taken in another order). */
+int ncx_train_tail(const ncx_dims* d, const ncx_params* p, void* workspace, size_t workspace_bytes, const int32_t* gt,
+                   float* scores, float* loss_rows, float* loss, float* dscores, int32_t* rank, int32_t* hits,
+                   const ncx_grads* g, void* stream);
 
 /* Gradient exchange of a data-parallel job (net-new: the reference is single-GPU; /root/reference/counterexamples.py:334-339
  * is where a DP job sums gradients between loss.backward() and optimizer.step()).  An opaque handle around one RCCL

@@ -438,3 +438,42 @@ def test_c_abi_rccl_handle_allreduce_on_one_rank():
     finally:
         _lib.comm_destroy(comm)
 
+
+@pytest.mark.parametrize("shape", [dict(B=20, K=24, H=64, L=1), dict(B=7, K=5, H=50, L=2), dict(B=33, K=32, H=256, L=1)])
+def test_fused_training_tail_equals_the_three_calls(shape):
+    """NCX_F_FUSED_TAIL (ncx_forward, ncx_train_tail, ncx_backward) against ncx_forward, ncx_loss_rank, ncx_backward: scores, loss,
+    ranks, hit counts and every gradient bit-identical (same per-lane arithmetic, same reductions), except d out.bias -- a sum
+    that is zero in mathematics, taken in another order."""
+    from neuralcx import ops, _lib
+    d = orc.Dims(K=shape["K"], dv=96, dq=64, dz=24, A=40, H=shape["H"], L=shape["L"])
+    params = orc.init_params(d, seed=12, gain=3.0)
+    batch = random_case(41, shape["B"], d)
+    b = to_dev_batch(batch)
+    p = to_dev_params(params)
+    gt = batch["gt"].to(dev()).to(torch.int32)
+
+    def run(fused):
+        dims = ops.make_dims(b, H=d.H, L=d.L, da=d.da, A=d.A, training=True, drop_p=0.25, loss_scale=1.0 / shape["B"], seed=77)
+        if fused:
+            assert ops.fused_tail_ok(dims)
+            dims.flags |= _lib.NCX_F_FUSED_TAIL
+        ws = ops.alloc_workspace(dims, dev())
+        g = {k: torch.full_like(v, float("nan")) for k, v in p.items()}
+        scores = ops.forward(dims, b, p, ws)
+        r = ops.train_tail(dims, p, ws, scores, gt, g, want_dscores=True) if fused else ops.ranking_loss(scores, gt, scale=1.0 / shape["B"])
+        ops.backward(dims, b, p, ws, None if fused else r["dscores"], g)
+        return scores, r, g
+
+    s0, r0, g0 = run(False)
+    s1, r1, g1 = run(True)
+    assert torch.equal(s0, s1)
+    for k in ("loss", "loss_rows", "dscores", "rank", "hits"):
+        assert torch.equal(r0[k], r1[k]), k
+    for k in g0:
+        if d.L < 3 and k in ("w3", "b3") or d.L < 2 and k in ("w2", "b2"):
+            continue
+        if k == "b_out":
+            assert abs(float(g0[k]) - float(g1[k])) <= 1e-6, k
+        else:
+            assert torch.equal(g0[k], g1[k]), k
+

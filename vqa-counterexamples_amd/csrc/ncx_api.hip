@@ -245,6 +245,10 @@ __global__ __launch_bounds__(256) void k_prep(ncx_dims d, ncx_inputs in, int* __
     }
 }
 
+// (explicit fma order: k_scores and k_train_tail must round identically)
+__device__ __forceinline__ float dot4(const f32x4& a, const f32x4& e) {
+    return __builtin_fmaf(a[3], e[3], __builtin_fmaf(a[2], e[2], __builtin_fmaf(a[1], e[1], a[0] * e[0])));
+}
 // scores[r] = h[r,:] . w + b     (cx.py:327); one wave per row.
 __global__ __launch_bounds__(256) void k_scores(const float* __restrict__ h, const float* __restrict__ w,
                                                 const float* __restrict__ bias, float* __restrict__ scores,
@@ -256,7 +260,7 @@ __global__ __launch_bounds__(256) void k_scores(const float* __restrict__ h, con
     float s = 0.f;
     for (int c = lane * 4; c < H; c += 256) {
         const f32x4 a = load4(row, c, H), e = load4(w, c, H);
-        s += a[0] * e[0] + a[1] * e[1] + a[2] * e[2] + a[3] * e[3];
+        s += dot4(a, e);
     }
     s = wave_sum(s);
     if (lane == 0) scores[r] = s + bias[0];
@@ -423,12 +427,13 @@ __global__ __launch_bounds__(256) void k_bwd_prelude(const float* __restrict__ g
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    if (k0 + j >= K) break;
-                    const f32x4 v = edge ? fix_window(hv[j], c, H) : hv[j];
-                    f32x4 dp;
+                    if (k0 + j < K) {
+                        const f32x4 v = edge ? fix_window(hv[j], c, H) : hv[j];
+                        f32x4 dp;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { dp[q] = v[q] > 0.f ? g[j] * w[q] * scale : 0.f; aw[q] += g[j] * v[q]; ds[q] += dp[q]; }
-                    put4(dpre + (r0 + k0 + j) * H, c, dp);
+                        for (int q = 0; q < 4; ++q) { dp[q] = v[q] > 0.f ? g[j] * w[q] * scale : 0.f; aw[q] = __builtin_fmaf(g[j], v[q], aw[q]); ds[q] += dp[q]; }
+                        put4(dpre + (r0 + k0 + j) * H, c, dp);
+                    }
                 }
             }
             if (dsh) { put4(dsh + (long long)b * H, c, ds); ab1 += ds; }
@@ -445,7 +450,29 @@ __global__ __launch_bounds__(256) void k_bwd_prelude(const float* __restrict__ g
 __global__ __launch_bounds__(256) void k_bwd_prelude_finish(const float* __restrict__ partial_w, const float* __restrict__ partial_b1,
                                                             const float* __restrict__ partial_b, int nblk, int H,
                                                             float* __restrict__ out_w, float* __restrict__ out_b1,
-                                                            float* __restrict__ out_b) {
+                                                            float* __restrict__ out_b, const float* __restrict__ loss_rows = nullptr,
+                                                            const int* __restrict__ rank = nullptr, int B = 0,
+                                                            float* __restrict__ loss = nullptr, int* __restrict__ hits = nullptr) {
+    if (blockIdx.y == 2) {                                  // ncx_train_tail: k_loss_finish's sums ride in this launch (same order)
+        if (blockIdx.x != 0) return;
+        __shared__ float sl[4];
+        __shared__ int s1[4], s5[4];
+        float acc = 0.f; int h1 = 0, h5 = 0;
+        for (int i = threadIdx.x; i < B; i += 256) {
+            if (loss_rows) acc += loss_rows[i];
+            if (rank) { const int rk = rank[i]; h1 += rk < 1; h5 += rk < 5; }
+        }
+        acc = wave_sum(acc);
+        h1 = (int)wave_sum((float)h1); h5 = (int)wave_sum((float)h5);
+        const int wq = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { sl[wq] = acc; s1[wq] = h1; s5[wq] = h5; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (loss) loss[0] = sl[0] + sl[1] + sl[2] + sl[3];
+            if (hits) { hits[0] = s1[0] + s1[1] + s1[2] + s1[3]; hits[1] = s5[0] + s5[1] + s5[2] + s5[3]; }
+        }
+        return;
+    }
     __shared__ float red[32][9];
     const int c = threadIdx.x & 7, g = threadIdx.x >> 3;
     const int which = blockIdx.y;                                   // 0: out.weight, 1: linear_1.bias
@@ -471,6 +498,91 @@ __global__ __launch_bounds__(256) void k_bwd_prelude_finish(const float* __restr
         __syncthreads();
         if (threadIdx.x == 0) out_b[0] = (sb[0] + sb[1]) + (sb[2] + sb[3]);
     }
+}
+
+// Training-step fusion (ncx_train_tail): the out layer, the listwise loss / rank and the backward prelude in ONE pass over h_L.
+// One wave per run of triplets, lane = 4 columns (H <= 256), the KB >= K rows of a triplet resident in registers:
+//   scores[b,k] = h[(b,k),:] . w_out + b_out                       (k_scores)
+//   loss_rows / dscores / rank of the triplet                      (k_loss_rank: lane k holds score k)
+//   dpre, dSh, partial sums of d out.weight / d out.bias / d linear_1.bias   (k_bwd_prelude, same wave partition)
+// Same per-lane arithmetic and the same wave reductions as the three kernels it replaces: scores, loss, ranks and every
+// gradient except d out.bias (a sum of zeros-in-maths; other order) are bit-identical to the unfused path.
+template <int KB>
+__global__ __launch_bounds__(64) void k_train_tail(const float* __restrict__ h, const float* __restrict__ w_out,
+                                                    const float* __restrict__ b_out, const int* __restrict__ gt, int B, int K, int H,
+                                                    float loss_scale, float gate_scale, float* __restrict__ scores,
+                                                    float* __restrict__ loss_rows, float* __restrict__ dscores, int* __restrict__ rank,
+                                                    float* __restrict__ dpre, float* __restrict__ dsh,
+                                                    float* __restrict__ partial_w, float* __restrict__ partial_b1,
+                                                    float* __restrict__ partial_b, float* __restrict__ zero_buf, long long zero_n) {
+    const int blk = blockIdx.x, nblk = gridDim.x;
+    if (zero_buf) {          // (as k_bwd_prelude: dGgt is scattered into zeros later in the backward)
+        const long long z0 = zero_n * blk / nblk / 4 * 4, z1 = blk + 1 == nblk ? zero_n : zero_n * (blk + 1) / nblk / 4 * 4;
+        for (long long i = z0 + 4 * threadIdx.x; i < z1; i += 256) {
+            if (i + 3 < z1) *(f32x4u*)(zero_buf + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+            else for (long long j = i; j < z1; ++j) zero_buf[j] = 0.f;
+        }
+    }
+    const int lane = threadIdx.x;                           // one wave per block: 512 triplets spread over all CUs, not 128 of them
+    const int wv = blk, nwv = nblk;
+    const int b0 = (int)((long long)B * wv / nwv), b1 = (int)((long long)B * (wv + 1) / nwv);
+    const int c = lane * 4;
+    const bool live = c < H, edge = c + 4 > H;
+    auto put4 = [&](float* p, const f32x4& v) __attribute__((always_inline)) {
+        if (c + 3 < H) *(f32x4u*)(p + c) = v;
+        else if (live) { p[c] = v[0]; if (c + 1 < H) p[c + 1] = v[1]; if (c + 2 < H) p[c + 2] = v[2]; }
+    };
+    const f32x4 w = fix_window(load_window(w_out, c, H), c, H);          // (lanes beyond H: all zeros)
+    const float bias = b_out[0];
+    f32x4 aw = {0.f, 0.f, 0.f, 0.f}, ab1 = {0.f, 0.f, 0.f, 0.f};
+    float sb = 0.f;
+    for (int b = b0; b < b1; ++b) {
+        const long long r0 = (long long)b * K;
+        f32x4 hv[KB];
+#pragma unroll
+        for (int k = 0; k < KB; ++k) hv[k] = load_window(h + (r0 + min(k, K - 1)) * H, c, H);
+        const int g = gt[b];
+        if (edge) {
+#pragma unroll
+            for (int k = 0; k < KB; ++k) hv[k] = fix_window(hv[k], c, H);
+        }
+        float sc = 0.f;
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            const float t = wave_sum(0.f + dot4(hv[k], w));
+            sc = lane == k ? t + bias : sc;
+        }
+        if (lane < K) scores[r0 + lane] = sc;
+        // listwise softmax cross-entropy + rank (k_loss_rank)
+        const float s = lane < K ? sc : -INFINITY;
+        const float m = wave_max(s);
+        const float e = lane < K ? __expf(s - m) : 0.f;
+        const float sum = wave_sum(e);
+        const float sg = __shfl(s, g, 64);
+        const float dsc = lane < K ? (e / sum - (lane == g ? 1.f : 0.f)) * loss_scale : 0.f;
+        if (dscores && lane < K) dscores[r0 + lane] = dsc;
+        const bool ahead = lane < K && (s > sg || (s == sg && lane < g));
+        const unsigned long long bal = __ballot(ahead);
+        if (lane == 0) { loss_rows[b] = (logf(sum) + m - sg) * loss_scale; rank[b] = __popcll(bal); }
+        sb += dsc;
+        // backward of out + dropout + relu (k_bwd_prelude)
+        f32x4 ds = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KB; ++k) {
+            if (k < K) {                                     // (uniform; a `break` would keep the loop rolled and hv[] in scratch)
+                const float gk = __shfl(dsc, k, 64);
+                f32x4 dp;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { dp[q] = hv[k][q] > 0.f ? gk * w[q] * gate_scale : 0.f; aw[q] = __builtin_fmaf(gk, hv[k][q], aw[q]); ds[q] += dp[q]; }
+                put4(dpre + (r0 + k) * H, dp);
+            }
+        }
+        if (dsh) { put4(dsh + (long long)b * H, ds); ab1 += ds; }
+    }
+    put4(partial_w + (long long)wv * H, aw);
+    if (dsh) put4(partial_b1 + (long long)wv * H, ab1);
+    sb = wave_sum(sb);
+    if (lane == 0) partial_b[wv] = sb;
 }
 
 // dsh[b][n] = sum_k dpre[b*K + k][n]
@@ -898,7 +1010,7 @@ static int check_dims(const ncx_dims* d) {
     if ((long long)d->B * d->K > (1ll << 30) / 4 || d->B > NCX_SCATTER_MAX_B) return NCX_E_DIMS;
     if (d->dv < 4 || d->dq < 4 || d->dz < 4 || d->da < 4 || d->A < 4 || d->H < 4 || d->K < 3) return NCX_E_DIMS;   // 16-byte windows
     if (d->drop_p < 0.f || d->drop_p >= 1.f) return NCX_E_DIMS;
-    if (d->flags & ~(NCX_F_ALL | NCX_F_BF16 | NCX_F_REUSE_GT)) return NCX_E_FLAGS;
+    if (d->flags & ~(NCX_F_ALL | NCX_F_BF16 | NCX_F_REUSE_GT | NCX_F_FUSED_TAIL)) return NCX_E_FLAGS;
     if ((d->flags & NCX_F_BF16) && (d->flags & NCX_F_ALL) != NCX_F_ALL) return NCX_E_FLAGS;    // bf16 variant: no lesions
     return NCX_OK;
 }
@@ -987,7 +1099,7 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
                 size_t workspace_bytes, float* scores, void* stream_) {
     int rc = check_dims(dp);
     if (rc != NCX_OK) return rc;
-    if (!in || !p || !workspace || !scores) return NCX_E_NULL;
+    if (!in || !p || !workspace || (!scores && !(dp->flags & NCX_F_FUSED_TAIL))) return NCX_E_NULL;
     const ncx_dims& d = *dp;
     const bool aemb = d.flags & NCX_F_A_EMB;
     if (!in->feats || !in->img_idx || !in->q_emb || !in->z_orig || !in->z_knns || !in->a_knns) return NCX_E_NULL;
@@ -1168,6 +1280,7 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
             if (rc) return rc;
         }
     }
+    if (d.flags & NCX_F_FUSED_TAIL) return NCX_OK;       // the out layer runs in ncx_train_tail
     hipLaunchKernelGGL(k_scores, dim3((unsigned)cdiv(M, 4)), dim3(256), 0, s, (const float*)(ws + w.h[d.L - 1]),
                        p->w_out, p->b_out, scores, M, H);
     NCX_HIP_TRY(hipGetLastError());
@@ -1187,6 +1300,51 @@ int ncx_loss_rank(const float* scores, const int32_t* gt, int32_t B, int32_t K, 
         hipLaunchKernelGGL(k_loss_finish, dim3(1), dim3(256), 0, s, (const float*)loss_rows, (const int*)rank, B, loss, hits);
         NCX_HIP_TRY(hipGetLastError());
     }
+    return NCX_OK;
+}
+
+int ncx_train_tail(const ncx_dims* dp, const ncx_params* p, void* workspace, size_t workspace_bytes, const int32_t* gt,
+                   float* scores, float* loss_rows, float* loss, float* dscores, int32_t* rank, int32_t* hits,
+                   const ncx_grads* g, void* stream_) {
+    int rc = check_dims(dp);
+    if (rc != NCX_OK) return rc;
+    if (!p || !workspace || !gt || !scores || !loss_rows || !rank || !g) return NCX_E_NULL;
+    if (!p->w_out || !p->b_out || !g->w_out || !g->b_out || !g->b1) return NCX_E_NULL;
+    const ncx_dims& d = *dp;
+    if (!(d.flags & NCX_F_FUSED_TAIL)) return NCX_E_FLAGS;
+    if (d.K > 32 || d.H > 256) return NCX_E_DIMS;            // the K rows of a triplet live in registers, one lane per 4 columns
+    const WsLayout w = ws_layout(d);
+    if (workspace_bytes < w.total || ((uintptr_t)workspace & 255)) return NCX_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream_;
+    char* ws = (char*)workspace;
+    const int H = d.H;
+    const bool aemb = d.flags & NCX_F_A_EMB;
+    const bool emb_nt = aemb && !(d.flags & NCX_F_BF16) && !hook_env("NCX_NO_EMB_NT");
+    const int Hp4 = pad_to(H, 4);
+    float* dagtT = (float*)(ws + w.dgtT) + (size_t)d.A * Hp4;
+    float* dagt = (float*)(ws + w.dagt);
+    float* partial = (float*)(ws + w.partial);
+    float* part_w = partial;
+    float* part_b1 = partial + (size_t)NCX_PRELUDE_WAVES * H;
+    float* part_b = partial + (size_t)NCX_PRELUDE_WAVES * H * 2;
+    const float dscale = (d.training && d.drop_p > 0.f) ? 1.f / (1.f - d.drop_p) : 1.f;
+    const float scale = d.loss_scale > 0.f ? d.loss_scale : 1.f / (float)d.B;
+    const int nblk = (int)cdiv(d.B < NCX_PRELUDE_WAVES ? d.B : NCX_PRELUDE_WAVES, 4);
+    const bool fuse_l1 = d.L == 1;
+    const float* hL = (const float*)(ws + w.h[d.L - 1]);
+    float* dpre = (float*)(ws + w.dpre[0]);
+    float* dsh = fuse_l1 ? (float*)(ws + w.dsh) : (float*)nullptr;
+    float* zb = emb_nt ? dagtT : aemb ? dagt : (float*)nullptr;
+    const long long zn = emb_nt ? (long long)d.A * Hp4 : (long long)H * d.A;
+#define NCX_TAIL_LAUNCH(KB) hipLaunchKernelGGL(k_train_tail<KB>, dim3(nblk * 4), dim3(64), 0, s, hL, p->w_out, p->b_out, gt, d.B, d.K, H, scale, dscale, \
+                                               scores, loss_rows, dscores, rank, dpre, dsh, part_w, part_b1, part_b, zb, zn)
+    if (d.K <= 8) NCX_TAIL_LAUNCH(8); else if (d.K <= 16) NCX_TAIL_LAUNCH(16); else if (d.K <= 24) NCX_TAIL_LAUNCH(24); else NCX_TAIL_LAUNCH(32);
+#undef NCX_TAIL_LAUNCH
+    NCX_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_bwd_prelude_finish, dim3((unsigned)cdiv(H, 8), 3), dim3(256), 0, s, (const float*)part_w, (const float*)part_b1,
+                       (const float*)part_b, nblk * 4, H, g->w_out, fuse_l1 ? g->b1 : (float*)nullptr, g->b_out,
+                       (const float*)loss_rows, (const int*)rank, d.B, loss, hits);
+    NCX_HIP_TRY(hipGetLastError());
     return NCX_OK;
 }
 
@@ -1215,7 +1373,7 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
                          size_t workspace_bytes, const float* dscores, const ncx_grads* g, void* stream_, int phase) {
     int rc = check_dims(dp);
     if (rc != NCX_OK) return rc;
-    if (!in || !p || !workspace || !dscores || !g) return NCX_E_NULL;
+    if (!in || !p || !workspace || !g || (!dscores && !(dp->flags & NCX_F_FUSED_TAIL))) return NCX_E_NULL;
     const ncx_dims& d = *dp;
     const bool aemb = d.flags & NCX_F_A_EMB;
     if (!g->answer_embedding || !g->w1 || !g->b1 || !g->w_out || !g->b_out) return NCX_E_NULL;
@@ -1260,6 +1418,8 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
     const bool do1 = phase != 2 && !only_de, do2 = phase != 1 && phase != 5 && !only_de;
     if (!do1) {                                       // phase 2: dpre_1 lives where phase 1 left it
         dpre = (float*)(ws + w.dpre[(d.L - 1) & 1]);
+    } else if (d.flags & NCX_F_FUSED_TAIL) {
+        // ncx_train_tail has produced dpre_L, dSh and the out-layer / linear_1.bias gradients
     } else {
         // one pass: dpre_L, d out.weight / d out.bias partials, and for L == 1 also dSh + d linear_1.bias partials
         const int nblk = (int)cdiv(d.B < NCX_PRELUDE_WAVES ? d.B : NCX_PRELUDE_WAVES, 4);      // one wave per run of triplets

@@ -13,12 +13,13 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libneuralcx_hip.so")
 NCX_F_V_MULT, NCX_F_V_DIST, NCX_F_V_RANK, NCX_F_A_EMB = 1, 2, 4, 8
 NCX_F_ALL = 15
 NCX_F_REUSE_GT = 32   # evaluation: Gt in the workspace is still valid (same weights)
+NCX_F_FUSED_TAIL = 64  # training: out layer + loss / Recall + head of the backward in one pass (ncx_train_tail)
 NCX_F_BF16 = 16       # BASELINE configs[4]: bf16 operands for the two dominant GEMMs (include/neuralcx.h)
 
 EXPORTS = ("ncx_input_size", "ncx_workspace_bytes", "ncx_forward", "ncx_loss_rank", "ncx_backward", "ncx_backward_phase",
            "ncx_adam_step", "ncx_version", "ncx_profile_begin", "ncx_profile_end", "ncx_plan_query",
            "ncx_vqa_workspace_bytes", "ncx_vqa_forward", "ncx_knn_workspace_bytes", "ncx_knn", "ncx_ws_region", "ncx_wgmap_check",
-           "ncx_comm_unique_id", "ncx_comm_create", "ncx_comm_destroy", "ncx_allreduce")
+           "ncx_comm_unique_id", "ncx_comm_create", "ncx_comm_destroy", "ncx_allreduce", "ncx_train_tail")
 
 
 class NcxDims(C.Structure):
@@ -111,6 +112,8 @@ def lib():
     L.ncx_profile_begin.argtypes = [C.c_uint32, C.c_int32]
     L.ncx_profile_end.restype = C.c_int
     L.ncx_profile_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int32]
+    L.ncx_train_tail.restype = C.c_int
+    L.ncx_train_tail.argtypes = [C.POINTER(NcxDims), C.POINTER(NcxParams), C.c_void_p, C.c_size_t] + [C.c_void_p] * 7 + [C.POINTER(NcxGrads), C.c_void_p]
     L.ncx_comm_unique_id.restype = C.c_int; L.ncx_comm_unique_id.argtypes = [C.c_void_p]
     L.ncx_comm_create.restype = C.c_int; L.ncx_comm_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
     L.ncx_comm_destroy.restype = C.c_int; L.ncx_comm_destroy.argtypes = [C.c_void_p]

@@ -16,7 +16,7 @@ from typing import Dict, Optional
 import torch
 
 from . import dp, ops
-from ._lib import NCX_F_ALL, NCX_F_A_EMB, NCX_F_BF16, NCX_F_REUSE_GT
+from ._lib import NCX_F_ALL, NCX_F_A_EMB, NCX_F_BF16, NCX_F_FUSED_TAIL, NCX_F_REUSE_GT
 
 STATE_NAMES = ("answer_embedding.weight", "linear_1.weight", "linear_1.bias", "linear_2.weight", "linear_2.bias",
                "linear_3.weight", "linear_3.bias", "out.weight", "out.bias")
@@ -72,6 +72,7 @@ class NeuralCXEngine:
         self.exp_avg_sq = torch.zeros_like(self.params.flat)
         self.step_count = 0
         self.world_size, self.pg = world_size, process_group
+        self.fused_tail = True                    # train_step: ncx_train_tail where the shape allows (tests switch it off to compare)
         self._ws = None
         self._ws_key = None
         self.seed = 42
@@ -150,8 +151,16 @@ class NeuralCXEngine:
         self.step_count += 1
         self._weights_version += 1
         d = self._dims(batch, True, 1.0 / gb)
+        # out layer + loss / Recall + head of the backward as one pass over h_L (ncx_train_tail) where the shape allows; a
+        # padding step (loss weight 0) takes the three separate calls
+        fused = active and self.fused_tail and ops.fused_tail_ok(d)
+        if fused:
+            d.flags |= NCX_F_FUSED_TAIL
         scores = ops.forward(d, batch, self.params.fields(), self._ws)
-        r = ops.ranking_loss(scores, gt, scale=1.0 / gb)
+        if fused:
+            r = ops.train_tail(d, self.params.fields(), self._ws, scores, gt, self.grads.fields())
+        else:
+            r = ops.ranking_loss(scores, gt, scale=1.0 / gb)
         if not active:
             for k in ("dscores", "loss", "loss_rows", "hits"):
                 r[k].zero_()

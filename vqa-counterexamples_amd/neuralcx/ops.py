@@ -138,7 +138,32 @@ def _ws_ptr(ws: torch.Tensor):
     return C.c_void_p(aligned), ws.numel() - (aligned - base)
 
 
+def fused_tail_ok(d: NcxDims) -> bool:
+    """Shapes ncx_train_tail takes (the K rows of a triplet live in registers, one lane per 4 columns)."""
+    return d.K <= 32 and d.H <= 256
+
+
+def train_tail(d: NcxDims, params: Dict[str, torch.Tensor], ws: torch.Tensor, scores: torch.Tensor, gt: torch.Tensor,
+               grads: Dict[str, torch.Tensor], want_dscores: bool = False):
+    """NCX_F_FUSED_TAIL: `out` + listwise loss / rank / Recall hits + the head of the backward in one pass (ncx_train_tail).
+    Fills `scores` (the tensor ops.forward returned untouched) and d out.weight / d out.bias (/ d linear_1.bias)."""
+    dev = scores.device
+    loss_rows = torch.empty(d.B, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    dscores = torch.empty_like(scores) if want_dscores else None
+    rank = torch.empty(d.B, dtype=torch.int32, device=dev)
+    hits = torch.empty(2, dtype=torch.int32, device=dev)
+    p, n = _ws_ptr(ws)
+    ps, gs = _params_struct(params, NcxParams), _params_struct(grads, NcxGrads)
+    _lib.check(_lib.lib().ncx_train_tail(C.byref(d), C.byref(ps), p, n, _ptr(gt, torch.int32, "gt"), C.c_void_p(scores.data_ptr()),
+                                         C.c_void_p(loss_rows.data_ptr()), C.c_void_p(loss.data_ptr()),
+                                         _ptr(dscores, torch.float32, "dscores"), C.c_void_p(rank.data_ptr()),
+                                         C.c_void_p(hits.data_ptr()), C.byref(gs), _stream()), "ncx_train_tail")
+    return dict(loss=loss, loss_rows=loss_rows, dscores=dscores, rank=rank, hits=hits)
+
+
 def forward(d: NcxDims, batch: Batch, params: Dict[str, torch.Tensor], ws: torch.Tensor) -> torch.Tensor:
+    """-> scores [B, K] (with NCX_F_FUSED_TAIL in d.flags: allocated here, written by train_tail)."""
     scores = torch.empty(d.B, d.K, dtype=torch.float32, device=batch.feats.device)
     p, n = _ws_ptr(ws)
     ins, ps = batch.c_struct(), _params_struct(params, NcxParams)
