@@ -31,11 +31,21 @@ __global__ __launch_bounds__(256) void k_pack_wc(ncx_dims d, Bf16Cols cc, SegOff
     wc[i] = to_bf16(v);
 }
 
+// 4 columns per thread (H % 4 == 0 and Hp % 4 == 0: one 16-byte load, one 8-byte store), else one
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_dpre_to_bf16(const float* __restrict__ x, int M, int H, int Hp, u16* __restrict__ y) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    constexpr int W = VEC ? 4 : 1;
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * W;
     if (i >= (long long)M * Hp) return;
     const int r = (int)(i / Hp), c = (int)(i - (long long)r * Hp);
-    y[i] = to_bf16(c < H ? x[(long long)r * H + c] : 0.f);
+    if (VEC) {
+        typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < H) v = *(const f32x4*)(x + (long long)r * H + c);
+        *(u16x4*)(y + i) = u16x4{to_bf16(v[0]), to_bf16(v[1]), to_bf16(v[2]), to_bf16(v[3])};
+    } else {
+        y[i] = to_bf16(c < H ? x[(long long)r * H + c] : 0.f);
+    }
 }
 
 // ---- NT: C[M, N] = A[M, Kc] . B[N, Kc]^T, both row-major bf16 (reduction along the contiguous dimension) ---------
@@ -328,7 +338,10 @@ int bf16_dw1c(const ncx_dims& d, const float* dpre, u16* dpre_bf, const u16* xc,
     const int M = d.B * d.K, Hp = (d.H + 127) / 128 * 128;
     {
         const long long n = (long long)M * Hp;
-        hipLaunchKernelGGL(k_dpre_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dpre, M, d.H, Hp, dpre_bf);
+        if (d.H % 4 == 0 && (((uintptr_t)dpre | (uintptr_t)dpre_bf) & 15) == 0)
+            hipLaunchKernelGGL(k_dpre_to_bf16<true>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, dpre, M, d.H, Hp, dpre_bf);
+        else
+            hipLaunchKernelGGL(k_dpre_to_bf16<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dpre, M, d.H, Hp, dpre_bf);
         NCX_HIP_TRY(hipGetLastError());
     }
     constexpr int BM = 128, BN = 128;
@@ -353,11 +366,20 @@ int bf16_dw1c(const ncx_dims& d, const float* dpre, u16* dpre_bf, const u16* xc,
 
 // ---- the answer-embedding products of the bf16 variant ------------------------------------------------------------
 // dst[r][c] = bf16(src[r*ld + c]) for r < R, c < C; zero elsewhere in the [Rp][Cp] image
+template <bool VEC>      // VEC: 4 columns per thread (C, Cp, ld multiples of 4, 16-byte aligned source rows)
 __global__ __launch_bounds__(256) void k_pack2d(const float* __restrict__ src, long long ld, int R, int C, u16* __restrict__ dst, int Rp, int Cp) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    constexpr int W = VEC ? 4 : 1;
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * W;
     if (i >= (long long)Rp * Cp) return;
     const int r = (int)(i / Cp), c = (int)(i - (long long)r * Cp);
-    dst[i] = to_bf16(r < R && c < C ? src[(long long)r * ld + c] : 0.f);
+    if (VEC) {
+        typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < R && c < C) v = *(const f32x4*)(src + (long long)r * ld + c);
+        *(u16x4*)(dst + i) = u16x4{to_bf16(v[0]), to_bf16(v[1]), to_bf16(v[2]), to_bf16(v[3])};
+    } else {
+        dst[i] = to_bf16(r < R && c < C ? src[(long long)r * ld + c] : 0.f);
+    }
 }
 // dst[c][r] = bf16(src[r][c]) (transposed image [C][Rp], zero for r >= R); 32x32 tiles through LDS, both sides coalesced
 __global__ __launch_bounds__(256) void k_pack_transposed(const float* __restrict__ src, int R, int C, u16* __restrict__ dst, int Rp) {
@@ -376,7 +398,10 @@ __global__ __launch_bounds__(256) void k_pack_transposed(const float* __restrict
 
 static int pack2d(const float* src, long long ld, int R, int C, u16* dst, int Rp, int Cp, hipStream_t s) {
     const long long n = (long long)Rp * Cp;
-    hipLaunchKernelGGL(k_pack2d, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, ld, R, C, dst, Rp, Cp);
+    if (C % 4 == 0 && Cp % 4 == 0 && ld % 4 == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0)
+        hipLaunchKernelGGL(k_pack2d<true>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, src, ld, R, C, dst, Rp, Cp);
+    else
+        hipLaunchKernelGGL(k_pack2d<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, ld, R, C, dst, Rp, Cp);
     NCX_HIP_TRY(hipGetLastError());
     return NCX_OK;
 }
