@@ -306,7 +306,16 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
             constexpr int S = decltype(set_c)::value;
             const int c = min(t, nst - 1) * BK + 4 * quad;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) { vk[S][i] = *(gf4ptr)(pk[i] + c); vo[S][i] = *(gf4ptr)(po[i] + c); vwk[S][i] = *(gf4ptr)(pwk[i] + c); vwm[S][i] = *(gf4ptr)(pwm[i] + c); }
+            for (int i = 0; i < 2; ++i) {
+#ifndef NCX_ABL_FOLD       // (tools/mb/mb_fold.hip timing ablations, results wrong: 1 no W_m loads, 2 no v_o loads, 3 no weight loads, 4 no v_k loads)
+                vk[S][i] = *(gf4ptr)(pk[i] + c); vo[S][i] = *(gf4ptr)(po[i] + c); vwk[S][i] = *(gf4ptr)(pwk[i] + c); vwm[S][i] = *(gf4ptr)(pwm[i] + c);
+#else
+                if (NCX_ABL_FOLD != 4 || t == 0) vk[S][i] = *(gf4ptr)(pk[i] + c);
+                if (NCX_ABL_FOLD != 2 || t == 0) vo[S][i] = *(gf4ptr)(po[i] + c);
+                if (NCX_ABL_FOLD != 3 || t == 0) vwk[S][i] = *(gf4ptr)(pwk[i] + c);
+                if ((NCX_ABL_FOLD != 3 && NCX_ABL_FOLD != 1) || t == 0) vwm[S][i] = *(gf4ptr)(pwm[i] + c);
+#endif
+            }
         };
         // part 0: the v_k rows + triplet 0's effective weights; part 1: triplet 1's
         auto vstash = [&](auto set_c, int buf, int part) __attribute__((always_inline)) {
