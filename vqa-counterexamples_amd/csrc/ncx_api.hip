@@ -970,8 +970,9 @@ WsLayout ws_layout(const ncx_dims& d) {
 // Internal side stream: independent small kernels (each under-fills 256 CUs, or is HBM-bound while the other is
 // MFMA-bound) are forked from the caller's stream and joined back with events, so the work stays fully ordered
 // with respect to `stream`.  One lazily created (stream, 2 events) triple per device.  Measured on MI355X at
-// configs[1]: 1.236-1.253 ms/step with it vs 1.221-1.228 without (the fork/join events cost what the overlap
-// wins), so it is OFF unless NCX_SIDE_STREAM=1.
+// configs[1]: round 1 (Gt, Sh || k_prep; dW1ak || dE) 1.236-1.253 ms/step with it vs 1.221-1.228 without; round 2 (the
+// whole answer-embedding chain || k_dw_km as well) 1.001-1.003 vs 0.985-0.992: the fork/join events cost what the
+// overlap wins and a full round of long workgroups leaves the short ones no slots, so it is OFF unless NCX_SIDE_STREAM=1.
 struct SideStream { hipStream_t s; hipEvent_t fork, join; int state; };     // state: 0 new, 1 ready, -1 unavailable
 static SideStream* side_stream() {
     static SideStream tab[16];
