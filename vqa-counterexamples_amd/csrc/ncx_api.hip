@@ -643,8 +643,14 @@ struct EmbPrepArgs {
     const float* src[3]; float* dst[3]; long long lds_[3]; int cols[3], ldd[3], dcols[3], tile0[4];   // transposes: src [H][cols] -> dst [cols][ldd], dst cols < dcols written
     int B, H, A, Hp4;
 };
-__global__ __launch_bounds__(256) void k_emb_prep(const EmbPrepArgs a) {
+// `fix` (valid: blocks beyond a.B + a.tile0[3]): the deferred split fix-up of the dW1[:, a_other] GEMM (64 x 64 tiles) rides along
+__global__ __launch_bounds__(256) void k_emb_prep(const EmbPrepArgs a, const FixupArgs fix) {
     __shared__ unsigned bits[NCX_SCATTER_MAX_B / 32 > 32 * 33 ? NCX_SCATTER_MAX_B / 32 : 32 * 33];     // scatter: id bitmap; transposes: a [32][33] tile
+    if ((int)blockIdx.x >= a.B + a.tile0[3]) {
+        const int id = blockIdx.x - (a.B + a.tile0[3]);
+        split_fixup_body<64, 64>(fix, id / 4, id % 4);
+        return;
+    }
     if ((int)blockIdx.x < a.B) {
         const int b = blockIdx.x, B = a.B;
         const int id = a.aid[b];
@@ -1167,6 +1173,10 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
         hipLaunchKernelGGL(k_prep<false>, dim3(prep_grid), dim3(256), 0, s, dprep, *in, idx_k, idx_o, idx_ob, mx, inv, misc, xc, bf16_cols(d), pk);
     NCX_HIP_TRY(hipGetLastError());
 
+    // Gt and Sh are two back-to-back split GEMMs on 64 x 64 tiles: their fix-ups (6 us each, mostly launch and ramp) run as one
+    FixupArgs fix_gt{}, fix_sh{};
+    const bool merge_fix = !ss && !bf16 && aemb && !(d.flags & NCX_F_REUSE_GT) && u[U_GT].plan.cfg == u[U_SH].plan.cfg &&
+                           !hook_env("NCX_NO_MERGE_FIX");
     // Gt[H, A] = W1[:, a_other] . E^T   (weights only: evaluation passes reuse it, NCX_F_REUSE_GT)
     if (aemb && bf16 && !(d.flags & NCX_F_REUSE_GT)) {       // bf16 copies of E / W1[:, a_*] (also the backward's operands)
         const Bf16Emb m = bf16_emb_layout(d, ws + w.bf_emb);
@@ -1179,7 +1189,9 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
         a.a[0] = x_plain(p->w1 + o.a_other, din, H, d.da);
         a.b[0] = x_plain(p->answer_embedding, d.da, d.A, d.da);
         a.klen[0] = d.da; a.out[0] = gt; a.ldo[0] = w.ldgt; a.n_cols[0] = d.A;
-        rc = run_gemm(U_GT, a, FORM_NT, u[U_GT].plan, slab_side, slab_side_bytes, nullptr, s2);
+        if (merge_fix) a.defer_fix = &fix_gt;                  // (its partial tiles wait in the side slab for the merged fix-up below)
+        rc = run_gemm(U_GT, a, FORM_NT, u[U_GT].plan, merge_fix ? (float*)(ws + w.slab2) : slab_side,
+                      merge_fix ? w.slab2_bytes : slab_side_bytes, nullptr, s2);
         if (rc) return rc;
     }
     // Sh[B, H] = b1 + shared segments
@@ -1194,8 +1206,10 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
                       : x_plain(in->a_emb_gt, d.da, d.B, d.da);
         a.b[3] = x_plain(p->w1 + o.a_gt, din, H, d.da); a.klen[3] = d.da;
         a.out[0] = sh; a.ldo[0] = H; a.n_cols[0] = H;
+        if (merge_fix) a.defer_fix = &fix_sh;
         rc = run_gemm(U_SH, a, FORM_NT, u[U_SH].plan, slab_side, slab_side_bytes, p->b1, s2);
         if (rc) return rc;
+        if (merge_fix) { rc = run_fixup2(fix_gt, fix_sh, u[U_SH].plan.cfg, s); if (rc) return rc; }   // Gt's and Sh's reductions: one launch
         if (ss) { rc = side_join(ss, s); if (rc) return rc; }
     }
     // h1 = drop(relu(Sh[b] + candidate segments))
@@ -1467,9 +1481,9 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
         rc = colsum(dsh, nullptr, d.B, H, g->b1); if (rc) return rc;
     }
     bool km_deferred = false;
-    auto run_km = [&]() -> int {
+    auto run_km = [&](bool finish = true) -> int {
         int r = prof_open(U_DW1C, s); if (r) return r;
-        r = dw_km(d, dpre, in->feats, idx_k, idx_o, (float*)(ws + w.km_slab), g->w1 + o.v_other, g->w1 + o.v_mult, din, s);
+        r = dw_km(d, dpre, in->feats, idx_k, idx_o, (float*)(ws + w.km_slab), g->w1 + o.v_other, g->w1 + o.v_mult, din, s, finish);
         if (r) return r;
         return prof_close(U_DW1C, s);
     };
@@ -1496,8 +1510,10 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
         // With the side stream the per-triplet fold kernel (a full round of long workgroups) is launched AFTER the grouped
         // launch, next to the answer-embedding chain (dW1ak, dE: short latency-bound workgroups) that waits for dGt.
         km_deferred = want_rest && km && aemb && do1 && do2 && side_stream() != nullptr;
+        // the sums over its k-chunk partials ride in one launch with the split fix-up of the grouped GEMM below
+        const bool km_merge = want_rest && km && !km_deferred && !hook_env("NCX_NO_MERGE_FIX");
         if (want_rest && km && !km_deferred) {      // v_other and v_mult columns in one MFMA pass (per-triplet fold)
-            rc = run_km(); if (rc) return rc;
+            rc = run_km(!km_merge); if (rc) return rc;
         }
         if (want_rest && !bf16 && !km) {
             add_c(x_gather(in->feats, d.dv, idx_k, M, d.dv), g->w1 + o.v_other, din);
@@ -1519,7 +1535,15 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
                   g->w1 + o.a_gt);
         }
         a.nseg = n;
+        FixupArgs fix_tn{};
+        if (km_merge) a.defer_fix = &fix_tn;
         if (n > 0) { rc = run_gemm(U_DW1C, a, FORM_TN, u[U_DW1C].plan, slab, w.slab_bytes, nullptr, s); if (rc) return rc; }
+        if (km_merge) {
+            rc = prof_open(U_DW1C, s); if (rc) return rc;
+            rc = dw_km_finish(d, (const float*)(ws + w.km_slab), g->w1 + o.v_other, g->w1 + o.v_mult, din, &fix_tn, u[U_DW1C].plan.cfg, s);
+            if (rc) return rc;
+            rc = prof_close(U_DW1C, s); if (rc) return rc;
+        }
         if (!(d.flags & NCX_F_V_MULT) && do2) {
             hipLaunchKernelGGL(k_zero_cols, dim3((unsigned)cdiv((long long)H * d.dv, 256)), dim3(256), 0, s, g->w1 + o.v_mult, H, din, d.dv);
             NCX_HIP_TRY(hipGetLastError());
@@ -1530,6 +1554,7 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
         // run there (own slab) while the caller's stream runs the per-triplet fold kernel
         SideStream* ss = km_deferred ? side_stream() : nullptr;
         hipStream_t se = ss ? ss->s : s;
+        FixupArgs fix_ak{};
         if (ss) { rc = side_fork(ss, s); if (rc) return rc; }
         const bool bf16e = d.flags & NCX_F_BF16;
         const Bf16Emb bm = bf16e ? bf16_emb_layout(d, ws + w.bf_emb) : Bf16Emb{};
@@ -1541,6 +1566,7 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
             GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = H;
             a.a[0] = x_plain(dgt, d.A, H, d.A); a.b[0] = x_plain(p->answer_embedding, d.da, d.A, d.da); a.klen[0] = d.A;
             a.out[0] = g->w1 + o.a_other; a.ldo[0] = din; a.n_cols[0] = d.da;
+            if (do1 && emb_nt && u[U_DW1AK].plan.cfg == CFG_64x64 && !hook_env("NCX_NO_MERGE_FIX")) a.defer_fix = &fix_ak;
             rc = run_gemm(U_DW1AK, a, FORM_NN, u[U_DW1AK].plan, ss ? (float*)(ws + w.slab2) : slab,
                           ss ? w.slab2_bytes : w.slab_bytes, nullptr, se); if (rc) return rc;
         }
@@ -1557,12 +1583,15 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
                 ea.tile0[e] = tiles; tiles += ((ldds[e] + 31) / 32) * ((colss[e] + 31) / 32);
             }
             ea.tile0[3] = tiles;
-            hipLaunchKernelGGL(k_emb_prep, dim3(d.B + tiles), dim3(256), 0, se, ea);
+            // (the dW1[:, a_other] GEMM above left its split fix-up to this launch)
+            hipLaunchKernelGGL(k_emb_prep, dim3(d.B + tiles + (fix_ak.valid ? fix_ak.grid_x * 4 : 0)), dim3(256), 0, se, ea, fix_ak);
+            fix_ak.valid = 0;
             NCX_HIP_TRY(hipGetLastError());
         } else if (do1) {   // dGgt = one-hot(aid)^T dSh   (dGgt was cleared by k_bwd_prelude)
             hipLaunchKernelGGL(k_scatter_dsh_by_answer, dim3(d.B), dim3(256), 0, se, (const float*)dsh, in->answer_aids, d.B, H, d.A, dagt);
             NCX_HIP_TRY(hipGetLastError());
         }
+        if (fix_ak.valid) { rc = run_fixup2(fix_ak, FixupArgs{}, CFG_64x64, se); if (rc) return rc; }      // (not picked up above)
         if (((do1 && !skip_de) || only_de) && bf16e) {
             rc = prof_open(U_DE, se); if (rc) return rc;
             rc = bf16_de(d, bm, dgt, g->answer_embedding, se); if (rc) return rc;

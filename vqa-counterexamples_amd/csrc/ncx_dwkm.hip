@@ -195,29 +195,40 @@ __global__ __launch_bounds__(256, OCC) void k_dw_km(const float* __restrict__ dp
 
 // Fixed-order sum of the k-chunk partials.  VEC: 4 consecutive columns per thread (dv % 4 == 0); all chunk loads are issued
 // before the first add (DW_KM_SPLIT is a compile-time bound: a runtime-length loop made every chunk a dependent round trip).
+struct KmReduceArgs { const float* slab; int nz, H, dv; long long din; float* g_vother; float* g_vmult; int nblk; };
 template <bool VEC>
-__global__ __launch_bounds__(256) void k_dw_km_reduce(const float* __restrict__ slab, int nz, int H, int dv, long long din,
-                                                      float* __restrict__ g_vother, float* __restrict__ g_vmult) {
+__device__ __forceinline__ void km_reduce_body(const KmReduceArgs& r, int blk) {
     constexpr int W = VEC ? 4 : 1;
     typedef float vec __attribute__((ext_vector_type(VEC ? 4 : 1)));
-    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * W, n = (long long)H * dv;
+    const long long i = ((long long)blk * 256 + threadIdx.x) * W, n = (long long)r.H * r.dv;
     if (i >= n) return;
-    const int h = (int)(i / dv), c = (int)(i - (long long)h * dv);
+    const int h = (int)(i / r.dv), c = (int)(i - (long long)h * r.dv);
     vec vk[DW_KM_SPLIT], vm[DW_KM_SPLIT];
 #pragma unroll
     for (int z = 0; z < DW_KM_SPLIT; ++z) {
-        const int zz = z < nz ? z : nz - 1;
-        vk[z] = *(const vec*)(slab + ((long long)zz * 2 + 0) * n + i);
-        vm[z] = *(const vec*)(slab + ((long long)zz * 2 + 1) * n + i);
+        const int zz = z < r.nz ? z : r.nz - 1;
+        vk[z] = *(const vec*)(r.slab + ((long long)zz * 2 + 0) * n + i);
+        vm[z] = *(const vec*)(r.slab + ((long long)zz * 2 + 1) * n + i);
     }
     vec sk = vk[0], sm = vm[0];
 #pragma unroll
-    for (int z = 1; z < DW_KM_SPLIT; ++z) { const vec zero = {}; sk += z < nz ? vk[z] : zero; sm += z < nz ? vm[z] : zero; }
+    for (int z = 1; z < DW_KM_SPLIT; ++z) { const vec zero = {}; sk += z < r.nz ? vk[z] : zero; sm += z < r.nz ? vm[z] : zero; }
 #pragma unroll
     for (int j = 0; j < W; ++j) {                        // (rows of linear_1.weight are din floats apart: not 16-byte aligned in general)
-        g_vother[(long long)h * din + c + j] = sk[j];
-        g_vmult[(long long)h * din + c + j] = sm[j];
+        r.g_vother[(long long)h * r.din + c + j] = sk[j];
+        r.g_vmult[(long long)h * r.din + c + j] = sm[j];
     }
+}
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_dw_km_reduce(const KmReduceArgs r) { km_reduce_body<VEC>(r, blockIdx.x); }
+// ... and, in the same launch, the split fix-up of the grouped GEMM that computes the other columns of linear_1's gradient
+// (two ~7-12 us reductions whose cost is mostly launch and ramp)
+template <bool VEC, int BM, int BN>
+__global__ __launch_bounds__(256) void k_dw_km_reduce_fixup(const KmReduceArgs r, const FixupArgs f) {
+    constexpr int NS = BM * BN / 1024;
+    if ((int)blockIdx.x < r.nblk) { km_reduce_body<VEC>(r, blockIdx.x); return; }
+    const int id = blockIdx.x - r.nblk;
+    split_fixup_body<BM, BN>(f, id / NS, id % NS);
 }
 
 bool dw_km_supported(const ncx_dims& d) {
@@ -229,11 +240,48 @@ bool dw_km_supported(const ncx_dims& d) {
 }
 size_t dw_km_slab_bytes(const ncx_dims& d) { return dw_km_supported(d) ? (size_t)DW_KM_SPLIT * 2 * d.H * d.dv * 4 : 0; }
 
-int dw_km(const ncx_dims& d, const float* dpre, const float* feats, const int* idx_k, const int* idx_o, float* slab,
-          float* g_vother, float* g_vmult, long long din, hipStream_t s) {
+static int km_chunks(const ncx_dims& d, int& chunk) {
     // up to 8 k-chunks (one per XCD), at least 16 triplets each: tiny batches are not worth 8 partial tiles
     const int S = d.B / 16 >= DW_KM_SPLIT ? DW_KM_SPLIT : (d.B / 16 >= 1 ? d.B / 16 : 1);
-    const int chunk = (d.B + S - 1) / S, nz = (d.B + chunk - 1) / chunk;
+    chunk = (d.B + S - 1) / S;
+    return S;
+}
+
+// The fixed-order sum of the k-chunk partials; `fix` (may be null / invalid): a deferred split fix-up of tile shape `fix_cfg` that
+// rides in the same launch.
+int dw_km_finish(const ncx_dims& d, const float* slab, float* g_vother, float* g_vmult, long long din, const FixupArgs* fix, int fix_cfg,
+                 hipStream_t s) {
+    int chunk; km_chunks(d, chunk);
+    KmReduceArgs r{};
+    r.slab = slab; r.nz = (d.B + chunk - 1) / chunk; r.H = d.H; r.dv = d.dv; r.din = din; r.g_vother = g_vother; r.g_vmult = g_vmult;
+    const long long n = (long long)d.H * d.dv;
+    const bool vec = d.dv % 4 == 0 && ((uintptr_t)slab & 15) == 0;      // 16-byte loads of the partials
+    r.nblk = (int)(((vec ? n / 4 : n) + 255) / 256);
+    const bool with_fix = fix && fix->valid && (fix_cfg == CFG_128x64 || fix_cfg == CFG_64x64);
+    if (!with_fix) {
+        if (vec) hipLaunchKernelGGL(k_dw_km_reduce<true>, dim3(r.nblk), dim3(256), 0, s, r);
+        else     hipLaunchKernelGGL(k_dw_km_reduce<false>, dim3(r.nblk), dim3(256), 0, s, r);
+        NCX_HIP_TRY(hipGetLastError());
+        if (fix && fix->valid) return run_fixup2(*fix, FixupArgs{}, fix_cfg, s);
+        return NCX_OK;
+    }
+    const int nfix = fix->grid_x * (fix_cfg == CFG_128x64 ? 8 : 4);
+    if (fix_cfg == CFG_128x64) {
+        if (vec) hipLaunchKernelGGL((k_dw_km_reduce_fixup<true, 128, 64>), dim3(r.nblk + nfix), dim3(256), 0, s, r, *fix);
+        else     hipLaunchKernelGGL((k_dw_km_reduce_fixup<false, 128, 64>), dim3(r.nblk + nfix), dim3(256), 0, s, r, *fix);
+    } else {
+        if (vec) hipLaunchKernelGGL((k_dw_km_reduce_fixup<true, 64, 64>), dim3(r.nblk + nfix), dim3(256), 0, s, r, *fix);
+        else     hipLaunchKernelGGL((k_dw_km_reduce_fixup<false, 64, 64>), dim3(r.nblk + nfix), dim3(256), 0, s, r, *fix);
+    }
+    NCX_HIP_TRY(hipGetLastError());
+    return NCX_OK;
+}
+
+// finish = false: the caller sums the partials later with dw_km_finish (merged with the grouped GEMM's fix-up)
+int dw_km(const ncx_dims& d, const float* dpre, const float* feats, const int* idx_k, const int* idx_o, float* slab,
+          float* g_vother, float* g_vmult, long long din, hipStream_t s, bool finish) {
+    int chunk;
+    const int S = km_chunks(d, chunk);
     constexpr int R = 24;
     // 128-row tiles at two workgroups per CU, or 64-row tiles at four (hook NCX_KM_BM=64)
     int bm = 128;
@@ -271,12 +319,7 @@ int dw_km(const ncx_dims& d, const float* dpre, const float* feats, const int* i
     if (bm == 128) rc = edge ? go(B128{}, O2{}, std::true_type{}) : go(B128{}, O2{}, std::false_type{});
     else           rc = edge ? go(B64{}, O4{}, std::true_type{}) : go(B64{}, O4{}, std::false_type{});
     if (rc) return rc;
-    const long long n = (long long)d.H * d.dv;
-    const bool vec = d.dv % 4 == 0 && ((uintptr_t)slab & 15) == 0;      // 16-byte loads of the partials
-    if (vec) hipLaunchKernelGGL(k_dw_km_reduce<true>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, (const float*)slab, nz, d.H, d.dv, din, g_vother, g_vmult);
-    else     hipLaunchKernelGGL(k_dw_km_reduce<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const float*)slab, nz, d.H, d.dv, din, g_vother, g_vmult);
-    NCX_HIP_TRY(hipGetLastError());
-    return NCX_OK;
+    return finish ? dw_km_finish(d, slab, g_vother, g_vmult, din, nullptr, 0, s) : NCX_OK;
 }
 
 }  // namespace ncx

@@ -91,6 +91,7 @@ struct EpiArgs {
     int rowsplit_g; float* out0; long long ldo0;
 };
 
+struct FixupArgs;
 struct GemmArgs {
     XDesc a[NCX_MAX_SEG];        // CHAIN: a[s] of pair s;  GROUP: a[i] of problem i
     XDesc b[NCX_MAX_SEG];
@@ -103,6 +104,7 @@ struct GemmArgs {
     int   wg0[NCX_MAX_SEG + 1];  // first workgroup id of problem i = sum tiles*split (filled by the launcher)
     int   mode, nseg, M, pad_;
     int   total_wgs;             // work items (filled by the launcher); the grid may be smaller: persistent loop
+    struct FixupArgs* defer_fix; // host only: when set, a split launch hands its fix-up back instead of launching it (merged fix-ups)
     int   pad2_;
     float* slab;                 // [workgroups][BM*BN] partial tiles of the split problems
     EpiArgs epi;
@@ -912,10 +914,12 @@ struct FixupArgs {
     const float* bias;
     const float* slab;
     int mode, nseg, M, act;      // act: 0 none, 1 relu, 2 tanh (applied after the bias)
+    int grid_x, valid;           // host: tiles of the launch; valid = a deferred fix-up is pending
 };
+// One block of the fix-up: `tile_blk` = tile index over the launch's problems, `slice` = which 1024-element slice of the tile
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void split_fixup_kernel(const FixupArgs a) {
-    int tile = blockIdx.x, prob = 0;
+__device__ __forceinline__ void split_fixup_body(const FixupArgs& a, int tile_blk, int slice) {
+    int tile = tile_blk, prob = 0;
     if (a.mode == MODE_GROUP) {
         while (prob + 1 < a.nseg && tile >= a.tile0[prob + 1]) ++prob;
         tile -= a.tile0[prob];
@@ -929,7 +933,7 @@ __global__ __launch_bounds__(256) void split_fixup_kernel(const FixupArgs a) {
     const long long ldo = a.ldo[prob];
     // one float4 per thread: blockIdx.y picks which 1024-element slice of the tile (BM*BN/1024 slices) -- small
     // problems have few tiles, so the slices are spread over blocks for memory-level parallelism
-    const int e = blockIdx.y * 1024 + threadIdx.x * 4;
+    const int e = slice * 1024 + threadIdx.x * 4;
     f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
     const WgMap wmap{(a.M + BM - 1) / BM, tiles_n, S};
     // k-chunk order: deterministic.  Eight partial tiles are requested before the first is added (one load per iteration of a
@@ -954,6 +958,25 @@ __global__ __launch_bounds__(256) void split_fixup_kernel(const FixupArgs a) {
             }
         }
     }
+}
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void split_fixup_kernel(const FixupArgs a) { split_fixup_body<BM, BN>(a, blockIdx.x, blockIdx.y); }
+// Two deferred fix-ups of the same tile shape in one launch (e.g. Gt and Sh: two back-to-back split GEMMs whose reductions are
+// ~6 us each, most of it launch and ramp)
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void split_fixup2_kernel(const FixupArgs a, const FixupArgs b) {
+    constexpr int NS = BM * BN / 1024;
+    const int id = blockIdx.x, na = a.grid_x * NS;
+    if (id < na) split_fixup_body<BM, BN>(a, id / NS, id % NS);
+    else         split_fixup_body<BM, BN>(b, (id - na) / NS, (id - na) % NS);
+}
+template <int BM, int BN>
+static inline hipError_t launch_fixup2(const FixupArgs& a, const FixupArgs& b, hipStream_t stream) {
+    constexpr int NS = BM * BN / 1024;
+    if (a.valid && b.valid) hipLaunchKernelGGL((split_fixup2_kernel<BM, BN>), dim3((a.grid_x + b.grid_x) * NS), dim3(256), 0, stream, a, b);
+    else if (a.valid)       hipLaunchKernelGGL((split_fixup_kernel<BM, BN>), dim3(a.grid_x, NS), dim3(256), 0, stream, a);
+    else if (b.valid)       hipLaunchKernelGGL((split_fixup_kernel<BM, BN>), dim3(b.grid_x, NS), dim3(256), 0, stream, b);
+    return hipGetLastError();
 }
 
 // ---- host-side launcher ---------------------------------------------------------------------------
@@ -1024,6 +1047,8 @@ static inline hipError_t launch_seg_gemm(GemmArgs& args, hipStream_t stream) {
     for (int i = 0; i < np; ++i) { f.out[i] = args.out[i]; f.ldo[i] = args.ldo[i]; f.n_cols[i] = args.n_cols[i]; f.split[i] = args.split[i]; }
     for (int i = 0; i <= np; ++i) { f.tile0[i] = args.tile0[i]; f.wg0[i] = args.wg0[i]; }
     f.bias = args.epi.bias; f.slab = args.slab; f.mode = args.mode; f.nseg = args.nseg; f.M = args.M; f.act = args.epi.relu;
+    f.grid_x = args.tile0[np]; f.valid = 1;
+    if (args.defer_fix) { *args.defer_fix = f; return hipSuccess; }      // the caller launches it (merged with another one)
     hipLaunchKernelGGL((split_fixup_kernel<BM, BN>), dim3(args.tile0[np], BM * BN / 1024), dim3(256), 0, stream, f);
     return hipGetLastError();
 }

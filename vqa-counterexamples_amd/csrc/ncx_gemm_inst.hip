@@ -18,6 +18,17 @@ int run_gemm_nt(GemmArgs& a, int cfg, hipStream_t s) {
 // chained pairs folded into a second accumulator (MUTAN fusion); 64x64 tiles: M = B*(K+1) rows x N = dim_mm
 int run_gemm_nt_fold(GemmArgs& a, hipStream_t s) { return (int)launch_seg_gemm<64, 64, true, true, true>(a, s); }
 
+// two deferred split fix-ups of one tile shape in one launch (either may be invalid = its GEMM was not split)
+int run_fixup2(const FixupArgs& a, const FixupArgs& b, int cfg, hipStream_t s) {
+    switch (cfg) {
+    case CFG_128x128: return (int)launch_fixup2<128, 128>(a, b, s);
+    case CFG_96x128:  return (int)launch_fixup2<96, 128>(a, b, s);
+    case CFG_96x64:   return (int)launch_fixup2<96, 64>(a, b, s);
+    case CFG_128x64:  return (int)launch_fixup2<128, 64>(a, b, s);
+    default:          return (int)launch_fixup2<64, 64>(a, b, s);
+    }
+}
+
 int occupancy_nt(int cfg) {
     static int occ[4] = {0, 0, 0, 0};
     if (!occ[cfg & 3]) {

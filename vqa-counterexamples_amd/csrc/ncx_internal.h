@@ -9,6 +9,7 @@ enum TileCfg : int { CFG_64x64 = 0, CFG_128x128 = 1, CFG_96x128 = 2, CFG_96x64 =
 enum GemmForm : int { FORM_NT = 0, FORM_TN = 1, FORM_NN = 2 };
 
 int run_gemm_nt(GemmArgs& a, int cfg, hipStream_t s);
+int run_fixup2(const FixupArgs& a, const FixupArgs& b, int cfg, hipStream_t s);
 int run_gemm_nt_fold(GemmArgs& a, hipStream_t s);
 int run_gemm_tn(GemmArgs& a, int cfg, hipStream_t s);
 int run_gemm_nn(GemmArgs& a, int cfg, hipStream_t s);
@@ -109,7 +110,9 @@ constexpr int DW_KM_SPLIT = 8;
 bool dw_km_supported(const ncx_dims& d);
 size_t dw_km_slab_bytes(const ncx_dims& d);
 int dw_km(const ncx_dims& d, const float* dpre, const float* feats, const int* idx_k, const int* idx_o, float* slab,
-          float* g_vother, float* g_vmult, long long din, hipStream_t s);
+          float* g_vother, float* g_vmult, long long din, hipStream_t s, bool finish = true);
+int dw_km_finish(const ncx_dims& d, const float* slab, float* g_vother, float* g_vmult, long long din, const FixupArgs* fix, int fix_cfg,
+                 hipStream_t s);
 WsLayout ws_layout(const ncx_dims& d);
 __host__ __device__ static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 // The fused forward kernel (ncx_main.h) takes operands whose widths are multiples of 4 (16-byte windows, no straddling);
