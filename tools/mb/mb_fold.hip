@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <vector>
 #include <algorithm>
+#include <math.h>
 using namespace ncx;
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 static float* dev_rand(size_t n, float scale, unsigned seed, bool positive = false) {
@@ -45,15 +46,34 @@ int main() {
     a.epi.rowadd = sh; a.epi.ld_rowadd = H; a.epi.rowdiv = K; a.epi.relu = 1;
     a.epi.dropout = 1; a.epi.drop_p = 0.25f; a.epi.drop_scale = 1.f / 0.75f; a.epi.seed_lo = 123; a.epi.seed_hi = 456; a.epi.layer = 1;
     typedef MainCfg<48, 64, 1, 4, 2, 2> CF;
+    typedef MainCfg<96, 64, 2, 2, 2, 2> CF4;
+    {   // the 96-row fold must reproduce the 48-row one bit for bit (same effective-weight expression, same k order)
+        float* out4; CHECK(hipMalloc(&out4, (size_t)M * H * 4));
+        MainArgs b = a; b.nseg = 4;
+        if (launch_main_fwd<CF>(b, 0) != 0) { printf("launch CF failed\n"); return 1; }
+        MainArgs c = a; c.nseg = 4; c.out = out4;
+        const int rc4 = launch_main_fwd<CF4>(c, 0);
+        if (rc4 != 0) { printf("launch CF4 failed: %d\n", rc4); return 1; }
+        CHECK(hipDeviceSynchronize());
+        std::vector<float> h0((size_t)M * H), h4((size_t)M * H);
+        CHECK(hipMemcpy(h0.data(), out, h0.size() * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(h4.data(), out4, h4.size() * 4, hipMemcpyDeviceToHost));
+        double md = 0; size_t nz = 0;
+        for (size_t i = 0; i < h0.size(); ++i) { md = std::max(md, (double)fabsf(h0[i] - h4[i])); nz += h0[i] != 0.f; }
+        printf("96-row fold vs 48-row fold: max |diff| %.3e over %zu outputs (%zu non-zero)\n", md, h0.size(), nz);
+    }
     struct V { const char* name; int nseg; std::vector<float> ms; };
-    std::vector<V> vs = {{"fold + misc + z + softmax (140 k-steps)", 4, {}}, {"fold + misc + z + misc (78 k-steps)", -4, {}}};
+    std::vector<V> vs = {{"fold + misc + z + softmax (140 k-steps)", 4, {}}, {"fold + misc + z + misc (78 k-steps)", -4, {}},
+                         {"96-row: fold + misc + z + softmax", 104, {}}, {"96-row: fold + misc + z + misc", -104, {}}};
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     for (int round = 0; round < 9; ++round)
         for (auto& v : vs) {
             MainArgs b = a; b.nseg = 4;
             if (v.nseg < 0) b.seg[3] = a.seg[1];                     // (V, P, P, P): the softmax segment replaced by a one-step plain one
-            { const int rc = launch_main_fwd<CF>(b, 0); if (rc != 0) { printf("launch failed: %d (%s)\n", rc, v.name); return 1; } }
-            CHECK(hipEventRecord(e0, 0)); for (int i = 0; i < 4; ++i) launch_main_fwd<CF>(b, 0); CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+            const bool four = v.nseg > 100 || v.nseg < -100;
+            { const int rc = four ? launch_main_fwd<CF4>(b, 0) : launch_main_fwd<CF>(b, 0); if (rc != 0) { printf("launch failed: %d (%s)\n", rc, v.name); return 1; } }
+            CHECK(hipEventRecord(e0, 0));
+            for (int i = 0; i < 4; ++i) { if (four) launch_main_fwd<CF4>(b, 0); else launch_main_fwd<CF>(b, 0); }
+            CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); v.ms.push_back(ms / 4);
         }
 #ifdef NCX_ABL_FOLD

@@ -1821,7 +1821,7 @@ int ncx_plan_query(const ncx_dims* d, int32_t gemm_id, int32_t* out6) {
         const int sp = main_split(M, d->H, T);
         const bool vfold = gemm_id == U_MAIN && (d->flags & NCX_F_V_MULT) && d->K == 24 && d->dv % 32 == 0 && d->dv >= 64 && sp == 1;
         const long long tiles96 = ((M + 95) / 96) * ((d->H + 127) / 128);
-        out6[4] = vfold ? 6 : (sp == 1 && tiles96 * 10 >= (long long)num_cus() * 9) ? CFG_96x128 : 5;
+        out6[4] = vfold ? (main_fold_rows(M, d->H) == 96 ? 7 : 6) : (sp == 1 && tiles96 * 10 >= (long long)num_cus() * 9) ? CFG_96x128 : 5;
         out6[5] = sp;
     }
     return NCX_OK;

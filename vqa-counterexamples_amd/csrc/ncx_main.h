@@ -45,7 +45,8 @@ struct MainCfg {
     static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, DEPTH = DEPTH_, OCC = OCC_;
     static constexpr int BM_LDS = (BM + 31) / 32 * 32;            // A rows held in LDS (a multiple of the 32-row loader pass)
     static constexpr int LDS = 2 * (BM_LDS + BN) * MF_P * 4;
-    static constexpr int LDS_FOLD = 2 * (80 + 2 * 64) * MF_P * 4;    // MK_VFOLD phase: A 80 rows, two effective weight tiles
+    static constexpr int LDS_FOLD = BM == 96 ? 2 * (128 + 128) * MF_P * 4      // MK_VFOLD on 96-row tiles: A 4 x 32 rows, W_k | W_m 2 x 64 rows
+                                             : 2 * (80 + 2 * 64) * MF_P * 4;    // MK_VFOLD on 48-row tiles: A 80 rows, two effective weight tiles
 };
 
 typedef const __attribute__((address_space(1))) float* gfptr;      // global address space: global_load, never flat_load
@@ -57,7 +58,8 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
     constexpr bool VFOLD = K0 == MK_VFOLD;
     constexpr int DIST_SEG = VFOLD ? 1 : 2;              // the (dist | rank) segment: right after the one that streams v_o and v_k
     static_assert(!DIST || (VFOLD ? K1 == MK_PLAIN : (K1 == MK_GATHER_MUL && K2 == MK_PLAIN)), "DIST: v_o, v_k segment followed by the dist | rank segment");
-    static_assert(!VFOLD || (CFG::BM == 48 && CFG::BN == 64 && CFG::WGM == 1 && CFG::WGN == 4 && CFG::DEPTH == 2), "fold: 48 x 64 tiles");
+    static_assert(!VFOLD || (CFG::BM == 48 && CFG::BN == 64 && CFG::WGM == 1 && CFG::WGN == 4 && CFG::DEPTH == 2) ||
+                            (CFG::BM == 96 && CFG::BN == 64 && CFG::WGM == 2 && CFG::WGN == 2 && CFG::DEPTH == 2 && !DIST), "fold: 48 x 64 or 96 x 64 tiles");
     constexpr int KS[6] = {K0, K1, K2, K3, K4, -1};
     constexpr int NSEG = K1 < 0 ? 1 : K2 < 0 ? 2 : K3 < 0 ? 3 : K4 < 0 ? 4 : 5;
     constexpr int BM = CFG::BM, BN = CFG::BN, BK = MF_BK, P = MF_P, DEPTH = CFG::DEPTH, BML = CFG::BM_LDS;
@@ -436,6 +438,146 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
         __syncthreads();
     };
 
+    // ---- MK_VFOLD on 96 x 64 tiles: FOUR triplets per workgroup, wave w = triplet w x all 64 columns --------------------------------
+    // The 48-row form materialises an effective weight tile per triplet in LDS and moves 32 KB from L2 per workgroup and k-step for
+    // 32 MFMAs per wave (8.7 flop per byte: the phase is bound by operand delivery, tools/mb/mb_fold.hip).  Here W_k and W_m go to
+    // LDS once for four triplets, v_o[w] rides in row 24 of triplet w's 32-row A block (rows 24..31 are padding: their outputs are
+    // dropped), and the effective-weight fragment is ONE fma per MFMA on the way from LDS to the matrix core:
+    //     b = fma(v_o[w][k], W_m[n][k], W_k[n][k])        (the same expression, hence the same bits, as the 48-row form)
+    // 28.8 KB per workgroup and k-step for 64 MFMAs per wave, 512 workgroups = one round at two per CU.
+    auto run_vfold4 = [&](const MainSeg& sg, const bool pf_next) __attribute__((always_inline)) {
+      if constexpr (VFOLD && BM == 96) {
+        constexpr int AR = 128, BR = 128;
+        float* const fa = mf_smem;                          // [2][AR][P]   triplet w: rows 32 w .. 32 w + 23 = v_k, row 32 w + 24 = v_o[w]
+        float* const fb = mf_smem + 2 * AR * P;             // [2][BR][P]   rows 0 .. 63 = W_k, 64 .. 127 = W_m (tile columns n0 ..)
+        const int klen = sg.klen, nst = klen / BK;
+        gfptr pA[4], pB[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                       // loader item i of this thread: A row trow + 32 i (triplet i), B row trow + 32 i
+            const int r = min(m0 + 24 * i + (trow < 24 ? trow : 0), M - 1);
+            pA[i] = (gfptr)sg.a + (long long)(trow < 24 ? ((giptr)sg.idx)[r] : ((giptr)sg.idx2)[r]) * sg.lda;
+            const int n = min(n0 + trow + 32 * (i & 1), N - 1);
+            pB[i] = (gfptr)(i < 2 ? sg.b : sg.b2) + (long long)n * sg.ldb;
+        }
+        f32x4 va4[2][4], vb4[2][4];
+        auto vissue = [&](auto set_c, int t) __attribute__((always_inline)) {
+            constexpr int SS_ = decltype(set_c)::value;
+            const int c = min(t, nst - 1) * BK + 4 * quad;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { va4[SS_][i] = *(gf4ptr)(pA[i] + c); vb4[SS_][i] = *(gf4ptr)(pB[i] + c); }
+        };
+        auto vstash = [&](auto set_c, int buf, int part) __attribute__((always_inline)) {      // part 0: the A rows, part 1: W_k | W_m
+            constexpr int SS_ = decltype(set_c)::value;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (part == 0) *(f32x4*)(fa + buf * AR * P + (trow + 32 * i) * P + 4 * quad) = va4[SS_][i];
+                else           *(f32x4*)(fb + buf * BR * P + (trow + 32 * i) * P + 4 * quad) = vb4[SS_][i];
+            }
+        };
+        f32x4 acc4[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        struct Frag { f32x2 a[2], wk[4], wm[4], vo; };
+        Frag x0, x1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) x1.a[i] = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x1.wk[j] = f32x2{0.f, 0.f}; x1.wm[j] = f32x2{0.f, 0.f}; }
+        x1.vo = f32x2{0.f, 0.f};
+        auto fread = [&](int buf, int s, Frag& x) __attribute__((always_inline)) {
+            const float* a = fa + buf * AR * P + (32 * wave + li) * P + 8 * s + 2 * lk;
+            const float* b = fb + buf * BR * P + li * P + 8 * s + 2 * lk;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) x.a[i] = *(const f32x2*)(a + i * 16 * P);
+            x.vo = *(const f32x2*)(fa + buf * AR * P + (32 * wave + 24) * P + 8 * s + 2 * lk);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { x.wk[j] = *(const f32x2*)(b + j * 16 * P); x.wm[j] = *(const f32x2*)(b + (64 + j * 16) * P); }
+        };
+        auto fmfma = [&](const Frag& x) __attribute__((always_inline)) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float bw = __builtin_fmaf(x.vo[e], x.wm[j][e], x.wk[j][e]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.a[i][e], bw, acc4[i][j], 0, 0, 0);
+                }
+        };
+        typedef IntC<0> V0; typedef IntC<1> V1;
+        vissue(V0{}, 0);
+        vissue(V1{}, 1);
+        vstash(V0{}, 0, 0); vstash(V0{}, 0, 1);
+        vissue(V0{}, 2);
+        __syncthreads();
+        auto vstep = [&](auto par_c, auto last_c, int t) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_c)::value;
+            constexpr bool LAST = decltype(last_c)::value;
+            typedef IntC<PAR ^ 1> SS;
+            fread(PAR, 0, x0);
+            fmfma(x1);                                                   // (t-1, last sub-step)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+            if (LAST && pf_next) {                                       // the next (plain) segment's first tiles
+                const MainSeg& nx = args.seg[1];
+                setup(IntC<K1 < 0 ? 0 : K1>{}, nx);
+                const int kn = nx.klen, nn = (kn + BK - 1) / BK;
+                issue(S0{}, Ff{}, kn, nn, 0);
+                issue(S1{}, Ff{}, kn, nn, 1);
+            }
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                Frag& cur = (s & 1) ? x1 : x0;
+                Frag& nxt = (s & 1) ? x0 : x1;
+                fread(PAR, s + 1, nxt);
+                if (!LAST) {
+                    if (s == 0) vstash(SS{}, PAR ^ 1, 0);
+                    if (s == 1) vstash(SS{}, PAR ^ 1, 1);
+                    if (s == 2) vissue(SS{}, t + 3);
+                }
+                fmfma(cur);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+        };
+        int t = 0;
+        for (; t + 2 < nst; t += 2) { vstep(V0{}, Ff{}, t); vstep(V1{}, Ff{}, t + 1); }
+        if (t + 1 < nst) { vstep(V0{}, Ff{}, t); vstep(V1{}, Tt{}, t + 1); }
+        else vstep(V0{}, Tt{}, t);
+        fmfma(x1);                                                       // the last sub-step
+        // padded (wave = triplet, 32 rows x 64 columns) -> compact (the 2 x 2 wave layout of the segments that follow), through LDS
+        constexpr int CP = 68;
+        float* const fc = mf_smem;                                       // [128 padded rows][CP]   (every fragment read is complete: last barrier)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fc[(32 * wave + 16 * i + 4 * lk + q) * CP + 16 * j + li] = acc4[i][j][q];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int rho = wm0 + 16 * i + 4 * lk + q;               // compact tile row 0 .. 95 = triplet rho / 24, candidate rho % 24
+                    acc[i][j][q] = fc[(32 * (rho / 24) + rho % 24) * CP + wn0 + 16 * j + li];
+                }
+        __syncthreads();
+      }
+    };
+
     // segment I runs its steps [lo, hi) = [g0, g1) intersected with the segment; the first one that has any loads its own
     // first tiles, every later one finds them loaded by its predecessor's last step
     bool started = false;
@@ -459,7 +601,8 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
         stamp(1 + I);
     };
     if constexpr (VFOLD) {
-        run_vfold(args.seg[0], NSEG > 1);
+        if constexpr (BM == 96) run_vfold4(args.seg[0], NSEG > 1);
+        else run_vfold(args.seg[0], NSEG > 1);
         base = nsteps[0]; started = true;
         stamp(1);
     } else {
@@ -618,6 +761,11 @@ static inline int launch_main_fwd(MainArgs& a, hipStream_t s) {
                 if (is({V, P, P, S})) return launch_main_fwd_seq<CFG, false, V, P, P, S>(a, s);
                 if (is({V, P, P, P})) return launch_main_fwd_seq<CFG, false, V, P, P, P>(a, s);
             }
+        }
+        if constexpr (CFG::BM == 96 && CFG::BN == 64 && CFG::WGM == 2 && CFG::DEPTH == 2) {      // four triplets per workgroup (run_vfold4)
+            if (a.split > 1 || a.seg[0].klen % MF_BK || a.seg[0].klen < 2 * MF_BK || !a.epi.rowadd || a.epi.rowdiv != 24 || a.dist_out) return NCX_E_FLAGS;
+            if (is({V, P, P, S})) return launch_main_fwd_seq<CFG, false, V, P, P, S>(a, s);
+            if (is({V, P, P, P})) return launch_main_fwd_seq<CFG, false, V, P, P, P>(a, s);
         }
         return NCX_E_FLAGS;
     }

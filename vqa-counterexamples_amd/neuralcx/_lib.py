@@ -164,7 +164,8 @@ def plan_query(d, name):
     out = (C.c_int32 * 6)()
     check(lib().ncx_plan_query(C.byref(d), GEMM_IDS[name], out), "ncx_plan_query")
     return dict(form=("NT", "TN", "NN")[out[0]], M=out[1], N=out[2], ksteps=out[3],
-                tile=("64x64", "128x128", "96x128", "96x64", "128x64", "48x128", "48x64 (per-triplet fold of the two v segments)")[out[4]], ksplit=out[5])
+                tile=("64x64", "128x128", "96x128", "96x64", "128x64", "48x128", "48x64 (per-triplet fold of the two v segments)",
+                      "96x64 (per-triplet fold of the two v segments, four triplets per workgroup)")[out[4]], ksplit=out[5])
 
 
 # ---- the C ABI's RCCL handle (include/neuralcx.h: ncx_comm_*, ncx_allreduce) ---------------------------------------------
