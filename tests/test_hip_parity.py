@@ -477,3 +477,27 @@ def test_fused_training_tail_equals_the_three_calls(shape):
         else:
             assert torch.equal(g0[k], g1[k]), k
 
+
+@pytest.mark.parametrize("K,fold4", [(24, "1"), (24, "0"), (48, "1")])
+def test_forward_fold_forms_vs_oracle(K, fold4, monkeypatch):
+    """The per-triplet forward fold (ncx_main.h, MK_VFOLD) in both tile forms -- 48-row (two triplets per workgroup, effective weight
+    tiles in LDS) and 96-row (four triplets at K = 24 / two at K = 48, v_o in the A block's spare row, effective weight = one fma per
+    MFMA operand) -- forced at a small size through the experiment hook, against the oracle; and the two forms against each other:
+    bit-identical (same expression, same k order).  B = 9 leaves the last 96-row tile ragged."""
+    from neuralcx import ops
+    monkeypatch.setenv("NCX_EXPERIMENT", "1")
+    monkeypatch.setenv("NCX_FOLD4", fold4)
+    d = orc.Dims(K=K, dv=96, dq=64, dz=24, A=40, H=64, L=1)
+    params = orc.init_params(d, seed=5, gain=3.0)
+    batch = random_case(77, 9, d)
+    b, p = to_dev_batch(batch), to_dev_params(params)
+    dims = ops.make_dims(b, H=d.H, L=d.L, da=d.da, A=d.A)
+    ws = ops.alloc_workspace(dims, dev())
+    scores = ops.forward(dims, b, p, ws).cpu()
+    ref = orc.forward_faithful(params, d, *[batch[k] for k in ("image_features", "q_emb", "z_orig", "z_knns", "a_knns", "answer_aids")])
+    assert (scores - ref.reshape(scores.shape)).abs().max() <= 1e-4
+    if K == 24:
+        monkeypatch.setenv("NCX_FOLD4", "1" if fold4 == "0" else "0")
+        other = ops.forward(dims, b, p, ws).cpu()
+        assert torch.equal(scores, other)
+

@@ -451,11 +451,15 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
         float* const fa = mf_smem;                          // [2][AR][P]   triplet w: rows 32 w .. 32 w + 23 = v_k, row 32 w + 24 = v_o[w]
         float* const fb = mf_smem + 2 * AR * P;             // [2][BR][P]   rows 0 .. 63 = W_k, 64 .. 127 = W_m (tile columns n0 ..)
         const int klen = sg.klen, nst = klen / BK;
+        // kr = 24: four triplets, 32-row blocks (24 v_k rows, v_o, 7 spare); kr = 48 (K = 48): two triplets, 64-row blocks (48 v_k rows,
+        // v_o, 15 spare) -- 4 MFMA row blocks per 48 rows against the 6 of the two plain segments, like 4 per 24 against 2 x 3
+        const int kr = args.epi.rowdiv, blk = kr == 24 ? 32 : 64;
         gfptr pA[4], pB[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {                       // loader item i of this thread: A row trow + 32 i (triplet i), B row trow + 32 i
-            const int r = min(m0 + 24 * i + (trow < 24 ? trow : 0), M - 1);
-            pA[i] = (gfptr)sg.a + (long long)(trow < 24 ? ((giptr)sg.idx)[r] : ((giptr)sg.idx2)[r]) * sg.lda;
+        for (int i = 0; i < 4; ++i) {                       // loader item i of this thread: A row trow + 32 i, B row trow + 32 i
+            const int lr = trow + 32 * i, tr = lr / blk, j = lr - tr * blk;     // LDS row -> (triplet of the tile, row of its block)
+            const int r = min(m0 + kr * tr + (j < kr ? j : 0), M - 1);
+            pA[i] = (gfptr)sg.a + (long long)(j < kr ? ((giptr)sg.idx)[r] : ((giptr)sg.idx2)[r]) * sg.lda;
             const int n = min(n0 + trow + 32 * (i & 1), N - 1);
             pB[i] = (gfptr)(i < 2 ? sg.b : sg.b2) + (long long)n * sg.ldb;
         }
@@ -486,12 +490,13 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
 #pragma unroll
         for (int j = 0; j < 4; ++j) { x1.wk[j] = f32x2{0.f, 0.f}; x1.wm[j] = f32x2{0.f, 0.f}; }
         x1.vo = f32x2{0.f, 0.f};
+        const int vo_row = kr == 24 ? 32 * wave + 24 : 64 * (wave >> 1) + 48;       // wave w: LDS rows 32 w .. 32 w + 31; its triplet's v_o row
         auto fread = [&](int buf, int s, Frag& x) __attribute__((always_inline)) {
             const float* a = fa + buf * AR * P + (32 * wave + li) * P + 8 * s + 2 * lk;
             const float* b = fb + buf * BR * P + li * P + 8 * s + 2 * lk;
 #pragma unroll
             for (int i = 0; i < 2; ++i) x.a[i] = *(const f32x2*)(a + i * 16 * P);
-            x.vo = *(const f32x2*)(fa + buf * AR * P + (32 * wave + 24) * P + 8 * s + 2 * lk);
+            x.vo = *(const f32x2*)(fa + buf * AR * P + vo_row * P + 8 * s + 2 * lk);
 #pragma unroll
             for (int j = 0; j < 4; ++j) { x.wk[j] = *(const f32x2*)(b + j * 16 * P); x.wm[j] = *(const f32x2*)(b + (64 + j * 16) * P); }
         };
@@ -571,8 +576,8 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
             for (int j = 0; j < WN; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int rho = wm0 + 16 * i + 4 * lk + q;               // compact tile row 0 .. 95 = triplet rho / 24, candidate rho % 24
-                    acc[i][j][q] = fc[(32 * (rho / 24) + rho % 24) * CP + wn0 + 16 * j + li];
+                    const int rho = wm0 + 16 * i + 4 * lk + q;               // compact tile row 0 .. 95 = triplet rho / kr, candidate rho % kr
+                    acc[i][j][q] = fc[(blk * (rho / kr) + rho % kr) * CP + wn0 + 16 * j + li];
                 }
         __syncthreads();
       }
@@ -763,7 +768,8 @@ static inline int launch_main_fwd(MainArgs& a, hipStream_t s) {
             }
         }
         if constexpr (CFG::BM == 96 && CFG::BN == 64 && CFG::WGM == 2 && CFG::DEPTH == 2) {      // four triplets per workgroup (run_vfold4)
-            if (a.split > 1 || a.seg[0].klen % MF_BK || a.seg[0].klen < 2 * MF_BK || !a.epi.rowadd || a.epi.rowdiv != 24 || a.dist_out) return NCX_E_FLAGS;
+            if (a.split > 1 || a.seg[0].klen % MF_BK || a.seg[0].klen < 2 * MF_BK || !a.epi.rowadd || (a.epi.rowdiv != 24 && a.epi.rowdiv != 48) || a.dist_out)
+                return NCX_E_FLAGS;
             if (is({V, P, P, S})) return launch_main_fwd_seq<CFG, false, V, P, P, S>(a, s);
             if (is({V, P, P, P})) return launch_main_fwd_seq<CFG, false, V, P, P, P>(a, s);
         }

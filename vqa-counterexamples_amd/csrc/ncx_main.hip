@@ -18,7 +18,7 @@ int main_forward(MainArgs& a, hipStream_t s) {
     if (a.nseg > 0 && a.seg[0].kind == MK_VFOLD) {
         // four triplets per workgroup when that still gives (nearly) two workgroups per CU; else two (twice the workgroups).
         // Measured at configs[1] (tools/mb/mb_fold.hip, bit-identical outputs): 293 us against 318.
-        bool four = main_fold_rows(a.M, a.N) == 96;
+        bool four = main_fold_rows(a.M, a.N) == 96 || a.epi.rowdiv == 48;      // (K = 48 exists on 96-row tiles only)
         if (const char* f4 = hook_env("NCX_FOLD4")) four = atoi(f4) != 0;
         return four ? launch_main_fwd<MainCfgFold4>(a, s) : launch_main_fwd<MainCfgFold>(a, s);
     }
