@@ -242,8 +242,9 @@ def main():
                  "DW1C": 2.0 * M * c["H"] * p_cols + 2.0 * args.batch * c["H"] * s_cols}   # all dW1 columns + dGt
         d0 = eng._dims(pool[0][0], True, 1.0 / gb)
         plans = {k: _lib.plan_query(d0, k) for k in ("MAIN", "DW1C")}
-        names = {"MAIN": "k_main_fwd (csrc/ncx_main.h): linear_1 forward, the five candidate segments chained into one fp32-MFMA accumulator, "
-                         "Sh / ReLU / Dropout epilogue",
+        names = {"MAIN": "k_main_fwd (csrc/ncx_main.h): linear_1 forward, the candidate segments chained into one fp32-MFMA accumulator "
+                         "(v_other and v_orig*v_other as one per-triplet fold where the plan says so), Sh / ReLU / Dropout epilogue; tile: %s"
+                         % plans["MAIN"]["tile"],
                  "DW1C": "linear_1 weight gradient (all columns + dGt): k_dw_km (v_other + v_mult columns in one MFMA pass, per-triplet "
                          "fold, 8 k-chunks) + seg_gemm TN %s grouped, %d-way aligned split-K (remaining columns), incl. reductions"
                          % (plans["DW1C"]["tile"], plans["DW1C"]["ksplit"])}
