@@ -1011,6 +1011,9 @@ static inline int seg_gemm_occupancy() {
     return n;
 }
 
+template <int BM, int BN>
+static inline hipError_t finish_split_launch(GemmArgs& args, hipStream_t stream);
+
 template <int BM, int BN, bool A_COLK, bool B_COLK, bool FOLD = false>
 static inline hipError_t launch_seg_gemm(GemmArgs& args, hipStream_t stream) {
     typedef GemmCfg<BM, BN, A_COLK, B_COLK> Cfg;
@@ -1042,6 +1045,12 @@ static inline hipError_t launch_seg_gemm(GemmArgs& args, hipStream_t stream) {
     hipLaunchKernelGGL((seg_gemm_kernel<BM, BN, A_COLK, B_COLK, FOLD>), dim3((unsigned)grid), dim3(256), Cfg::LDS_BYTES, stream, args);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || !any_split) return e;
+    return finish_split_launch<BM, BN>(args, stream);
+}
+
+// The fix-up of a split launch whose layout (tile0 / wg0) is in `args`: launched here, or handed to the caller (defer_fix).
+template <int BM, int BN>
+static inline hipError_t finish_split_launch(GemmArgs& args, hipStream_t stream) {
     FixupArgs f{};
     const int np = args.mode == MODE_GROUP ? args.nseg : 1;
     for (int i = 0; i < np; ++i) { f.out[i] = args.out[i]; f.ldo[i] = args.ldo[i]; f.n_cols[i] = args.n_cols[i]; f.split[i] = args.split[i]; }
