@@ -478,16 +478,17 @@ def test_fused_training_tail_equals_the_three_calls(shape):
             assert torch.equal(g0[k], g1[k]), k
 
 
+@pytest.mark.parametrize("H", [64, 300])
 @pytest.mark.parametrize("K,fold4", [(24, "1"), (24, "0"), (48, "1")])
-def test_forward_fold_forms_vs_oracle(K, fold4, monkeypatch):
+def test_forward_fold_forms_vs_oracle(K, fold4, H, monkeypatch):
     """The per-triplet forward fold (ncx_main.h, MK_VFOLD) in both tile forms -- 48-row (two triplets per workgroup, effective weight
     tiles in LDS) and 96-row (four triplets at K = 24 / two at K = 48, v_o in the A block's spare row, effective weight = one fma per
     MFMA operand) -- forced at a small size through the experiment hook, against the oracle; and the two forms against each other:
-    bit-identical (same expression, same k order).  B = 9 leaves the last 96-row tile ragged."""
+    bit-identical (same expression, same k order).  B = 9 leaves the last 96-row tile ragged, H = 300 the last column tile (44 of 64)."""
     from neuralcx import ops
     monkeypatch.setenv("NCX_EXPERIMENT", "1")
     monkeypatch.setenv("NCX_FOLD4", fold4)
-    d = orc.Dims(K=K, dv=96, dq=64, dz=24, A=40, H=64, L=1)
+    d = orc.Dims(K=K, dv=96 if H == 64 else 160, dq=64, dz=24, A=40, H=H, L=1)
     params = orc.init_params(d, seed=5, gain=3.0)
     batch = random_case(77, 9, d)
     b, p = to_dev_batch(batch), to_dev_params(params)
