@@ -76,6 +76,50 @@ int main() {
             CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); v.ms.push_back(ms / 4);
         }
+    {   // in-kernel stamps of one 96-row launch: where does a workgroup's time go?
+        const int grid = ((M + 95) / 96 + 7) / 8 * 8 * (H / 64);
+        unsigned long long* st; CHECK(hipMalloc(&st, (size_t)grid * 16 * 8)); CHECK(hipMemset(st, 0, (size_t)grid * 16 * 8));
+        MainArgs b = a; b.nseg = 4; b.stamps = st;
+        launch_main_fwd<CF4>(b, 0); CHECK(hipDeviceSynchronize());
+        std::vector<unsigned long long> h((size_t)grid * 16);
+        CHECK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long r0 = ~0ull, r1 = 0;
+        for (int g = 0; g < grid; ++g) if (h[g * 16 + 15]) { r0 = std::min(r0, h[g * 16 + 14]); r1 = std::max(r1, h[g * 16 + 15]); }
+        double sum[6] = {0, 0, 0, 0, 0, 0}, clk = 0, mn = 1e9, mx = 0; int cnt = 0;
+        for (int g = 0; g < grid; ++g) {
+            const unsigned long long* w = &h[g * 16];
+            if (!w[15]) continue;
+            const double dur = (w[15] - w[14]) / 100.0;
+            mn = std::min(mn, dur); mx = std::max(mx, dur);
+            clk += (double)(w[8] - w[0]) / ((w[15] - w[14]) * 10.0);
+            for (int i = 0; i < 4; ++i) sum[i] += (double)(w[1 + i] - w[i]);
+            sum[5] += (double)(w[8] - w[4]);
+            ++cnt;
+        }
+        printf("-- stamps (96-row fold): kernel span %.1f us, %d workgroups, duration %.1f .. %.1f us, mean clock %.2f GHz\n", (r1 - r0) / 100.0, cnt, mn, mx, clk / cnt);
+        {   // who is slow?  per XCD: mean / max duration and mean fold-phase cycles; per column tile (id >> 3) % 4 likewise
+            double dx[8] = {0}, mxx[8] = {0}, fx[8] = {0}; int nx[8] = {0};
+            double dt[4] = {0}, ft[4] = {0}; int nt[4] = {0};
+            for (int g = 0; g < grid; ++g) {
+                const unsigned long long* w = &h[g * 16];
+                if (!w[15]) continue;
+                const int x = (int)(w[13] & 7), tnn = (g >> 3) % 4;
+                const double dur = (w[15] - w[14]) / 100.0;
+                dx[x] += dur; mxx[x] = std::max(mxx[x], dur); fx[x] += (double)(w[1] - w[0]); ++nx[x];
+                dt[tnn] += dur; ft[tnn] += (double)(w[1] - w[0]); ++nt[tnn];
+            }
+            for (int x = 0; x < 8; ++x) if (nx[x]) printf("   xcd %d: %3d workgroups  mean %.1f  max %.1f us  fold phase %.0f cycles\n", x, nx[x], dx[x] / nx[x], mxx[x], fx[x] / nx[x]);
+            for (int t = 0; t < 4; ++t) if (nt[t]) printf("   column tile %d: mean %.1f us  fold phase %.0f cycles\n", t, dt[t] / nt[t], ft[t] / nt[t]);
+            int hist[10] = {0};
+            for (int g = 0; g < grid; ++g) if (h[g * 16 + 15]) { const double dur = (h[g * 16 + 15] - h[g * 16 + 14]) / 100.0; int b = (int)((dur - mn) / (mx - mn + 1e-9) * 10); hist[b > 9 ? 9 : b]++; }
+            printf("   duration histogram (%.0f .. %.0f us in 10 bins):", mn, mx); for (int b = 0; b < 10; ++b) printf(" %d", hist[b]); printf("\n");
+        }
+        const char* nm[6] = {"fold(v)", "misc", "z", "softmax", "-", "epilogue"};
+        const int ks[6] = {64, 1, 12, 63, 1, 1}, mf[6] = {64, 48, 48, 48, 1, 1};
+        for (int i = 0; i < 6; ++i) if (i != 4)
+            printf("   %-10s mean %9.0f cycles  %7.0f per k-step  (%d MFMAs per wave and step x 32 cycles x 2 workgroups per SIMD = %d)\n",
+                   nm[i], sum[i] / cnt, sum[i] / cnt / ks[i], mf[i], mf[i] * 64);
+    }
 #ifdef NCX_ABL_FOLD
     printf("ablation %d:", NCX_ABL_FOLD);
 #else
