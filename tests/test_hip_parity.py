@@ -287,6 +287,15 @@ def test_configs1_full_size_every_logit_and_gradient_vs_oracle():
     compare_with_oracle(d, None, params, batch)
 
 
+def test_ragged_full_width_batch_vs_oracle():
+    """B = 389 at configs[1]'s widths: 9 336 candidate rows = 97 whole 96-row tiles + one with a single triplet (the four-triplet
+    forward fold's ragged last tile), an odd number of triplets for the weight-gradient chunks, a batch the wave-per-triplet tail
+    kernels do not divide evenly.  Every logit and every gradient against the oracle, same bounds as the configs[1] test."""
+    d = orc.Dims()
+    params, batch = _full_size_case(d, 389, 777)
+    compare_with_oracle(d, None, params, batch)
+
+
 def test_configs4_shape_fp32_and_bf16_vs_oracles():
     """BASELINE configs[4] at its stated shape (K = 48 candidates, B = 1024, full widths): the fp32 path against the
     faithful oracle with the fp32 tolerances, and the bf16-operand variant against the oracle's bf16 restatement
