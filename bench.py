@@ -23,10 +23,28 @@ for _p in (ROOT, os.path.join(ROOT, "vqa-counterexamples_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import torch
-
 PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # same table, "Peak BF16/FP16 MFMA" (dense)
+
+
+def launch_ranks(n, argv, env=None, timeout=None):
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks ourselves, exactly as the contract's
+    launch line does (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py <same flags>), as a CHILD process.  This parent makes no GPU call of any kind (torch is not even imported
+    here) and never re-execs; it relays the children's output (rank 0 prints the one JSON line) and returns the child's
+    exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                     # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ if env is None else env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("bench.py: WORLD_SIZE unset and --gpus %d: launching %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env, timeout=timeout).returncode
 
 
 def usable_cores():
@@ -43,57 +61,96 @@ def usable_cores():
     return int(env) if env else min(n, 16)
 
 
-def cpu_baseline(steps=50, warmup=10, one_thread_steps=12, heldout=None):
+def cpu_baseline(dev, feats, steps=50, warmup=10, one_thread_steps=12, heldout=1024):
     """Reference-faithful CPU path (oracle.FaithfulCPUModel: 24-iteration cat+Linear loop, softmax+bmm, autograd,
     torch.optim.Adam) at BASELINE configs[0] (B=32, H=256, L=1, full widths), the protocol of BASELINE.md 3 on a bounded
-    sample: all usable cores, `warmup` untimed + `steps` timed steps (>= 50), then a short 1-thread run, loss and
-    Recall@1/@5 of the CPU-trained model on `heldout` (dict of CPU tensors) after the pass."""
-    from oracle import ncx_oracle as orc
+    sample: all usable cores, `warmup` untimed + `steps` timed steps (>= 50), then a short 1-thread run.
+
+    The other half of BASELINE.json's metric, Recall@1/@5, on the SAME footing for both sides: the CPU model and a fresh
+    HIP engine start from the same weights and train on the same `warmup + steps` planted synthetic batches with the
+    same dropout masks (the counter-based generator, restated in the oracle), then both score the same `heldout`
+    held-out triplets.  (tests/test_dropin_gpu.py holds the long version of this comparison with its assertions.)"""
     import numpy as np
+    import torch
+    from oracle import ncx_oracle as orc
+    from neuralcx.engine import NeuralCXEngine
+    from neuralcx.synth import SyntheticCX
     d = orc.Dims()
-    B = 32
+    B, p_drop, lr = 32, 0.25, 1e-4
     torch.manual_seed(42)
     threads = usable_cores()
-    m = orc.FaithfulCPUModel(d, drop_p=0.25, seed=42)
+    n_train = warmup + steps
+    data = SyntheticCX(n_triplets=B * n_train + heldout, K=d.K, n_img=feats.shape[0], seed=977, device=dev, feats=feats)
+    feats_cpu = feats.cpu()
+
+    def to_cpu(b, gt):
+        return dict(image_features=feats_cpu[b.img_idx.cpu().long()], q_emb=b.q_emb.cpu(), z_orig=b.z_orig.cpu(), z_knns=b.z_knns.cpu(),
+                    a_knns=b.a_knns.cpu(), answer_aids=b.answer_aids.cpu().long(), gt=gt.cpu().long())
+    # ---- HIP side: the same weights, batches and dropout masks ------------------------------------------------------------
+    params0 = orc.init_params(d, seed=42)
+    eng = NeuralCXEngine(K=d.K, H=d.H, L=d.L, drop_p=p_drop, lr=lr, device=dev)
+    eng.load_state(params0)
+    cpu_batches = []
+    for s in range(n_train):
+        b, gt = data.batch(torch.arange(s * B, (s + 1) * B, device=dev), first_id=s * B)
+        eng.train_step(b, gt)
+        cpu_batches.append(to_cpu(b, gt))
+    hits = torch.zeros(2, dtype=torch.int64, device=dev)
+    held_cpu = []
+    for lo in range(0, heldout, 256):
+        hi = min(lo + 256, heldout)
+        b, gt = data.batch(torch.arange(B * n_train + lo, B * n_train + hi, device=dev), first_id=B * n_train + lo)
+        ev = eng.eval_step(b, gt)
+        hits += ev["hits"].long()
+        held_cpu.append(to_cpu(b, gt))
+    hip_rec = (float(hits[0]) / heldout, float(hits[1]) / heldout)
+    hip_loss = float(ev["loss"])
+    del eng
+    # ---- CPU side ------------------------------------------------------------------------------------------------------------
+    m = orc.FaithfulCPUModel(d, drop_p=p_drop, seed=42)
     m.train()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
-    rng = np.random.default_rng(1234)
-    pool = []
-    for _ in range(4):                        # a few distinct batches, cycled
-        pool.append(((torch.randn(B, d.K + 1, d.dv).abs() * 0.45), torch.randn(B, d.dq) * 0.3, torch.randn(B, d.dz), torch.randn(B, d.K, d.dz),
-                     torch.randn(B, d.K, d.A) * 2, torch.from_numpy(rng.integers(0, d.A, size=B)), torch.from_numpy(rng.integers(0, d.K, size=B))))
+    opt = torch.optim.Adam(m.parameters(), lr=lr)
 
     def step(i):
-        feats, q, zo, zk, ak, aid, gt = pool[i % len(pool)]
-        scores = m(feats, q, zo, zk, ak, aid)
-        loss = torch.nn.functional.cross_entropy(scores, gt, reduction="sum") / B
+        bt = cpu_batches[i]
+        m.keep_masks = [orc.dropout_keep_mask((42 << 32) ^ (i + 1), 1, B * d.K, d.H, p_drop)]       # the engine's per-step seed (rank 0)
+        scores = m(bt["image_features"], bt["q_emb"], bt["z_orig"], bt["z_knns"], bt["a_knns"], bt["answer_aids"])
+        loss = torch.nn.functional.cross_entropy(scores, bt["gt"], reduction="sum") / B
         opt.zero_grad(); loss.backward(); opt.step()
         return float(loss)
-
-    def timed(nthreads, nwarm, nsteps):
-        torch.set_num_threads(nthreads)
-        for i in range(nwarm):
-            step(i)
-        t0 = time.perf_counter()
-        for i in range(nsteps):
-            loss = step(nwarm + i)
-        return B * nsteps / (time.perf_counter() - t0), loss
-    rate, loss = timed(threads, warmup, steps)
-    rate1, _ = timed(1, 1, one_thread_steps)
-    out = dict(value=round(rate, 2), unit="triplets/s", cores=threads, kind="port",
-               one_thread=dict(value=round(rate1, 2), unit="triplets/s", cores=1, steps=one_thread_steps),
-               final_loss=round(loss, 5),
-               sample="%d timed train steps of batch 32 after %d warm-up (configs[0] shapes: K=24, 2048-d feats, H=256, L=1, dropout 0.25, "
-                      "Adam lr 1e-4), torch %s CPU, %d threads; then %d steps on 1 thread" % (steps, warmup, torch.__version__, threads, one_thread_steps))
-    if heldout is not None:
-        torch.set_num_threads(threads)
-        m.eval()
-        with torch.no_grad():
-            s = m(heldout["image_features"], heldout["q_emb"], heldout["z_orig"], heldout["z_knns"], heldout["a_knns"], heldout["answer_aids"])
-        rank = orc.rank_of_gt(s.numpy(), heldout["gt"].numpy())
-        out["recall_at_1"], out["recall_at_5"] = round(float((rank < 1).mean()), 4), round(float((rank < 5).mean()), 4)
-        out["heldout_triplets"] = int(rank.shape[0])
-    return out
+    torch.set_num_threads(threads)
+    for i in range(warmup):
+        step(i)
+    t0 = time.perf_counter()
+    for i in range(warmup, n_train):
+        loss = step(i)
+    rate = B * steps / (time.perf_counter() - t0)
+    m.eval()
+    ranks = []
+    with torch.no_grad():
+        for h in held_cpu:
+            sc = m(h["image_features"], h["q_emb"], h["z_orig"], h["z_knns"], h["a_knns"], h["answer_aids"])
+            ranks.append(orc.rank_of_gt(sc.numpy(), h["gt"].numpy()))
+    rank = np.concatenate(ranks)
+    cpu_rec = (float((rank < 1).mean()), float((rank < 5).mean()))
+    m.train()
+    torch.set_num_threads(1)                         # 1-thread figure (the weights no longer matter)
+    step(0)
+    t0 = time.perf_counter()
+    for i in range(one_thread_steps):
+        step(1 + i % (n_train - 1))
+    rate1 = B * one_thread_steps / (time.perf_counter() - t0)
+    torch.set_num_threads(threads)
+    return dict(value=round(rate, 2), unit="triplets/s", cores=threads, kind="port",
+                one_thread=dict(value=round(rate1, 2), unit="triplets/s", cores=1, steps=one_thread_steps),
+                final_loss=round(loss, 5),
+                sample="%d timed train steps of batch 32 after %d warm-up (configs[0] shapes: K=24, 2048-d feats, H=256, L=1, dropout 0.25, "
+                       "Adam lr 1e-4), torch %s CPU, %d threads; then %d steps on 1 thread" % (steps, warmup, torch.__version__, threads, one_thread_steps),
+                recall=dict(note="both sides: the same initial weights, the same %d batches of 32 planted synthetic triplets, the same dropout masks; "
+                                 "then the same %d held-out triplets (chance 0.0417 / 0.2083)" % (n_train, heldout),
+                            cpu_recall_at_1=round(cpu_rec[0], 4), cpu_recall_at_5=round(cpu_rec[1], 4),
+                            hip_recall_at_1=round(hip_rec[0], 4), hip_recall_at_5=round(hip_rec[1], 4),
+                            train_steps=n_train, heldout_triplets=heldout))
 
 
 def workload_label(args, c):
@@ -125,20 +182,25 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=50, help="timed all-core steps of the CPU baseline (after 10 warm-up)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --batch triplets per rank; strong: --batch triplets globally (batch / N per rank)")
-    ap.add_argument("--heldout", type=int, default=1024, help="held-out planted triplets for Recall@1/@5 after the timed steps")
+    ap.add_argument("--heldout", type=int, default=1024, help="held-out planted triplets for Recall@1/@5 (after the timed steps; and of the CPU/HIP same-training comparison)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: this process becomes the launcher of the N ranks (no GPU call here)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                             "--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ..." % (args.gpus, args.gpus))
         raise SystemExit("--gpus (%d) != WORLD_SIZE (%d)" % (args.gpus, world))
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the HIP path)")
     backend = os.environ.get("NCX_DIST_BACKEND", "nccl")               # "gloo": rehearsal of N ranks on one card
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit("bench.py --gpus %d: RCCL needs one GPU per rank and this box exposes %d (two ranks on one device are "
+                         "rejected by RCCL); set NCX_DIST_BACKEND=gloo to rehearse %d ranks on one card"
+                         % (world, torch.cuda.device_count(), world))
     local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -213,11 +275,13 @@ def main():
         lt = torch.tensor([loss], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(lt)
         loss = float(lt.item())
+    # HIP events of the timed launches are read BEFORE anything else launches the same kernels (round 2's line summed the
+    # MAIN launches of the 4 evaluation batches below into the timed steps' total: 0.344 ms reported for a 0.30 ms kernel)
+    prof = _lib.profile_end() if rank == 0 else None
     # Recall@1/@5 (the other half of BASELINE.json's metric) of the weights after warmup + steps, on held-out triplets of the
     # same planted synthetic distribution (rank 0's replica; replicas are identical)
-    heldout_cpu, rec = None, None
+    rec = None
     if rank == 0 and args.heldout > 0 and mutan is None:
-        from neuralcx import ops
         hd = SyntheticCX(n_triplets=args.heldout, K=args.K, n_img=args.n_img, seed=4321, device=dev, feats=data.feats)
         hits = torch.zeros(2, dtype=torch.int64, device=dev)
         hb = 256
@@ -225,15 +289,33 @@ def main():
             b, gt = hd.batch(torch.arange(lo, min(lo + hb, args.heldout)))
             ev = eng.eval_step(b, gt)
             hits += ev["hits"].long()
-            if lo == 0 and not args.no_cpu_baseline and world == 1:       # the same first 256 triplets go to the CPU-trained model
-                heldout_cpu = dict(image_features=b.feats[b.img_idx.long()].cpu(), q_emb=b.q_emb.cpu(), z_orig=b.z_orig.cpu(),
-                                   z_knns=b.z_knns.cpu(), a_knns=b.a_knns.cpu(), answer_aids=b.answer_aids.long().cpu(), gt=gt.long().cpu())
         rec = (float(hits[0]) / args.heldout, float(hits[1]) / args.heldout)
 
     if rank == 0:
-        prof = _lib.profile_end()
         c = eng.cfg
         M = args.batch * c["K"]
+        # Diagnostic pass AFTER the timed region (never inside it): the shader clock the chip holds while the step runs
+        # back to back, from in-kernel stamps of MAIN (ncx_profile_stamps: s_memtime / s_memrealtime at entry and exit of
+        # every workgroup of the last of `nd` further steps).  Ranks > 0 of a multi-GPU run idle at the final barrier.
+        clock = None
+        if not args.bf16 and world == 1:
+            nd = 12
+            st = torch.zeros(16 * 8192, dtype=torch.int64, device=dev)
+            _lib.profile_stamps(st)
+            for i in range(nd):
+                step(args.warmup + args.steps + i)
+            torch.cuda.synchronize()
+            _lib.profile_stamps(None)
+            w = st.view(-1, 16).cpu()
+            w = w[(w[:, 15] > w[:, 14]) & (w[:, 8] > w[:, 0])]
+            if w.shape[0]:
+                mhz = (w[:, 8] - w[:, 0]).double() / (w[:, 15] - w[:, 14]).double() * 100.0
+                dur = (w[:, 15] - w[:, 14]).double() / 100.0
+                clock = dict(sclk_mhz=round(float(mhz.median()), 1), sclk_mhz_min=round(float(mhz.min()), 1), sclk_mhz_max=round(float(mhz.max()), 1),
+                             workgroups=int(w.shape[0]), workgroup_us_median=round(float(dur.median()), 1),
+                             kernel_span_us=round(float(w[:, 15].max() - w[:, 14].min()) / 100.0, 1),
+                             how="in-kernel stamps of the last of %d back-to-back diagnostic steps after the timed region: "
+                                 "d(s_memtime) / d(s_memrealtime) x 100 MHz per workgroup, median" % nd)
         # Algorithmic flops per launch (SURVEY 8d conventions: one-hot rank columns = 0 flops; the a_emb_other
         # segment is consumed in its re-associated form softmax(a) . (E . W^T): A columns instead of da).
         p_cols = 2 * c["dv"] + 1 + c["dz"] + c["A"]                     # candidate segments
@@ -261,22 +343,53 @@ def main():
         # pair must not outrank the one launch that is longer than either of them)
         per_launch = {k: sum(v) / len(v) for k, v in prof.items() if v}
         dom = max(per_launch, key=per_launch.get) if per_launch else None
+        # flops the matrix cores EXECUTE for `flops` (padding of reduction extents to 32; the per-triplet folds run 32
+        # (K = 24) or 64 (K = 48) row blocks per triplet for the two 2048-deep segments at once: 4 MFMA row blocks instead of 2 x 3)
+        pad32 = lambda n: (n + 31) // 32 * 32
+        rest_cols = pad32(c["K"] + 1) + pad32(c["dz"]) + pad32(c["A"])
+        fold_fwd = plans["MAIN"]["tile"].startswith(("48x64", "96x64"))
+        blk = 32 if c["K"] == 24 else 64
+        executed = {"MAIN": 2.0 * c["H"] * ((args.batch * blk if fold_fwd else 2 * M) * c["dv"] + M * rest_cols),
+                    "DW1C": (2.0 * c["H"] * M * (c["dv"] + c["K"] + 1 + c["dz"] + c["A"]) + 2.0 * args.batch * c["H"] * s_cols) if c["K"] % 24 == 0 and args.batch >= 256
+                            else flops["DW1C"]}
         roof = None
         if dom:
             ach = flops[dom] / (per[dom] * 1e-3) / 1e12
             # HBM bytes per launch of that kernel from the committed PMC passes (collected offline as the guide
-            # prescribes: separate --pmc runs, FETCH_SIZE x2 on gfx950); only valid for the default workload
+            # prescribes: separate --pmc runs, FETCH_SIZE x2 on gfx950), per workload
             traffic, traffic_source = None, None
-            tpath = os.path.join(ROOT, "profiles", "r2_traffic.json")
-            if os.path.exists(tpath) and (args.batch, c["K"], c["H"], c["L"]) == (512, 24, 256, 1) and not args.bf16:
-                tj = json.load(open(tpath))
-                traffic = tj.get(dom, {}).get("bytes_per_launch")
-                traffic_source = "profiles/r2_traffic.json: %s" % tj.get("_source", "rocprofv3 --pmc passes of this workload")
+            wl = "c5" if (args.bf16 and (args.batch, c["K"]) == (1024, 48)) else "c3" if args.c3 else \
+                 "c2" if (args.batch, c["K"], c["H"], c["L"], args.bf16) == (512, 24, 256, 1, False) else None
+            for tname in ("r3_traffic.json", "r2_traffic.json"):
+                tpath = os.path.join(ROOT, "profiles", tname)
+                if wl and os.path.exists(tpath):
+                    tj = json.load(open(tpath))
+                    tj = tj.get(wl, tj if wl == "c2" else {})
+                    if tj.get(dom, {}).get("bytes_per_launch"):
+                        traffic = tj[dom]["bytes_per_launch"]
+                        traffic_source = "profiles/%s: %s" % (tname, tj.get("_source", "rocprofv3 --pmc passes of this workload"))
+                        break
+            # spread over the timed launches (per step: DW1C sums its two launches)
+            nl = max(1, len(prof[dom]) // args.steps)
+            series = [sum(prof[dom][i * nl:(i + 1) * nl]) for i in range(args.steps)]
+            srt = sorted(series)
+            k5 = min(5, len(series))
             roof = dict(bound="mfma", kernel=names[dom], achieved=round(ach, 2), peak=peak,
                         unit="TFLOP/s", frac=round(ach / peak, 4), traffic=traffic, traffic_source=traffic_source,
-                        launch_ms=round(per[dom], 4), algorithmic_gflop_per_launch=round(flops[dom] / 1e9, 3),
+                        launch_ms=round(per[dom], 4), launch_ms_min=round(srt[0], 4), launch_ms_median=round(srt[len(srt) // 2], 4),
+                        launch_ms_max=round(srt[-1], 4), launch_ms_first5=round(sum(series[:k5]) / k5, 4),
+                        launch_ms_last5=round(sum(series[-k5:]) / k5, 4),
+                        algorithmic_gflop_per_launch=round(flops[dom] / 1e9, 3),
                         other={k: dict(launch_ms=round(v, 4), launches_per_step=len(prof[k]) // args.steps, tflops=round(flops[k] / (v * 1e-3) / 1e12, 2),
-                                       plan=plans[k]) for k, v in per.items()})
+                                       mfma_executed_gflop=round(executed[k] / 1e9, 3), plan=plans[k]) for k, v in per.items()})
+            if not args.bf16:
+                ex = executed[dom] / (per[dom] * 1e-3) / 1e12
+                roof.update(mfma_executed_gflop=round(executed[dom] / 1e9, 3), executed_tflops=round(ex, 2), frac_executed=round(ex / peak, 4),
+                            peak_assumes_mhz=2400)
+                if clock:
+                    held = peak * clock["sclk_mhz"] / 2400.0
+                    roof.update(clock, peak_at_held_clock=round(held, 1), frac_of_peak_at_held_clock=round(ach / held, 4),
+                                frac_executed_at_held_clock=round(ex / held, 4))
         out = dict(metric="VQA-CX triplets/sec (24 candidates each), NeuralCX training step",
                    value=round(gb * args.steps / dt, 1), unit="triplets/s", n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 4), higher_is_better=True,
@@ -287,15 +400,23 @@ def main():
                                         "2048-d feats, %d candidates, batch %d per GPU (%s scaling: global batch %d), H=%d, L=%d, dropout 0.25, %s"
                                         % (c["K"], args.batch, args.scaling, gb, c["H"], c["L"],
                                            "bf16 operands / fp32 accumulate for the linear_1 and answer-embedding products, fp32 elsewhere" if args.bf16 else "fp32"),
-                               global_batch=gb, candidates=c["K"], dim_h=c["H"], n_layers=c["L"],
+                               global_batch=gb, per_rank_batch=args.batch, candidates=c["K"], dim_h=c["H"], n_layers=c["L"],
                                parallelism="dp%d" % world, feature_table_rows=args.n_img, final_loss=round(loss, 5)),
                    roofline=roof)
         if rec is not None:
             out["recall_at_1"], out["recall_at_5"] = round(rec[0], 4), round(rec[1], 4)
             out["recall_note"] = ("HIP path, %d held-out planted synthetic triplets, after %d training steps (chance: 0.0417 / 0.2083)"
                                   % (args.heldout, args.warmup + args.steps))
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(steps=args.cpu_steps, heldout=heldout_cpu)
+        if world > 1:
+            if backend == "nccl":
+                v = torch.cuda.nccl.version()
+                out["rccl"] = dict(nranks=world, version=".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v),
+                                   collective="sum all-reduce per step: dGt|dGgt block (%.1f MB) + flat gradient without answer_embedding (%.1f MB)"
+                                              % (2 * c["H"] * ((c["A"] + 3) // 4 * 4) * 4 / 1e6, (eng.params.numel - eng.params.offsets["linear_1.weight"]) * 4 / 1e6))
+            else:
+                out["rccl"] = dict(nranks=world, version=None, note="NCX_DIST_BACKEND=%s rehearsal: NOT RCCL" % backend)
+        if not args.no_cpu_baseline and world == 1 and (c["dv"], c["K"]) == (2048, 24):
+            out["cpu_baseline"] = cpu_baseline(dev, data.feats, steps=args.cpu_steps, heldout=args.heldout)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

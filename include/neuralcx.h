@@ -264,6 +264,14 @@ int ncx_knn(const float* table, int32_t n, const float* queries, int32_t nq, int
 #define NCX_GEMM_DXL 10
 int ncx_profile_begin(uint32_t gemm_mask /* bit i = gemm id i */, int32_t max_launches);
 int ncx_profile_end(float* ms, int32_t* ids, int32_t cap);
+/* In-kernel clock diagnostics of the MAIN launch (the fused forward kernel of linear_1): while `stamps` is non-NULL
+ * every fp32 MAIN launch makes thread 0 of each workgroup write 16 uint64 words to stamps[16 * workgroup id ...]:
+ * word 0 = shader-cycle counter (s_memtime) at kernel entry, word 8 = the same at exit, words 14 / 15 = the 100 MHz
+ * constant-rate counter (s_memrealtime) at entry / exit, word 13 = XCC id.  The clock a workgroup held is
+ * (w8 - w0) / (w15 - w14) x 100 MHz.  `words` = capacity of the device buffer in uint64 (>= 16 x workgroups of the
+ * launch, else the launch is not stamped).  ncx_profile_stamps(NULL, 0) disarms.  The timed product path never arms it
+ * (bench.py stamps a separate diagnostic pass after its timed region). */
+int ncx_profile_stamps(unsigned long long* stamps, int64_t words);
 /* out6 = {form (0 NT,1 TN,2 NN), M, N, 32-deep k-steps, tile cfg (0 64x64, 1 128x128, 2 96x128),
  *         aligned k-chunks per output tile (1 = no split)} */
 int ncx_plan_query(const ncx_dims* d, int32_t gemm_id, int32_t* out6);

@@ -419,11 +419,15 @@ def train_step(params, d: Dims, batch, state: AdamState, lr=1e-4, spec=None, dro
 class FaithfulCPUModel(torch.nn.Module):
     """nn.Module wrapper around :func:`forward_faithful` with torch's own Dropout, so the CPU
     baseline executes the same operator sequence as cx.py:280-331 + counterexamples.py:325-339
-    (24-iteration cat+Linear loop, softmax+bmm expected embedding, autograd, optim.Adam)."""
+    (24-iteration cat+Linear loop, softmax+bmm expected embedding, autograd, optim.Adam).
+    ``keep_masks`` (a list of [B*K, H] keep masks, one per hidden layer, e.g. from :func:`dropout_keep_mask`) replaces
+    torch's Dropout stream by the counter-based one the HIP kernels use, so that a HIP run and this model can be trained
+    on identical batches with identical dropout (bench.py's Recall comparison); None = nn.Dropout."""
 
     def __init__(self, d: Dims, drop_p: float = 0.25, seed: int = 42):
         super().__init__()
         self.d, self.drop_p = d, drop_p
+        self.keep_masks = None
         p = init_params(d, seed)
         self.answer_embedding = torch.nn.Embedding(d.A, d.da)
         self.linear_1 = torch.nn.Linear(d.din, d.H)
@@ -450,8 +454,10 @@ class FaithfulCPUModel(torch.nn.Module):
             x = torch.cat((v_orig, v_other, v_orig * v_other,
                            F.pairwise_distance(v_orig, v_other, keepdim=True), v_rank, q_emb,
                            z_orig, z_knns[:, i], a_emb_gt, a_emb_knns[:, i]), dim=1)
-            h = self.drop(F.relu(self.linear_1(x)))
-            if d.L >= 2: h = self.drop(F.relu(self.linear_2(h)))
-            if d.L >= 3: h = self.drop(F.relu(self.linear_3(h)))
+            km = self.keep_masks if self.training else None
+            drop = (lambda h, l: h * km[l].view(B, d.K, d.H)[:, i] / (1.0 - self.drop_p)) if km is not None else (lambda h, l: self.drop(h))
+            h = drop(F.relu(self.linear_1(x)), 0)
+            if d.L >= 2: h = drop(F.relu(self.linear_2(h)), 1)
+            if d.L >= 3: h = drop(F.relu(self.linear_3(h)), 2)
             scores.append(self.out(h))
         return torch.cat(scores, dim=1)

@@ -1028,6 +1028,8 @@ static int check_dims(const ncx_dims* d) {
 // -------------------------------------------------------------------------------------------------
 struct ProfState { bool on; unsigned mask; int n, cap; hipEvent_t* ev; int* ids; };
 static ProfState g_prof = {false, 0u, 0, 0, nullptr, nullptr};
+static unsigned long long* g_stamps = nullptr;      // ncx_profile_stamps: in-kernel clock stamps of MAIN (diagnostic passes only)
+static long long g_stamp_words = 0;
 
 static int run_gemm_impl(GemmArgs& a, int form, const GemmPlan& pl, float* slab, size_t slab_bytes,
                          const float* reduce_bias, hipStream_t s);
@@ -1249,6 +1251,7 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
             a.split = main_split(M, H, T); a.slab = (float*)(ws + w.mslab);
             if (a.split > 1 && (size_t)a.split * M * H * 4 > w.mslab_bytes) return NCX_E_WORKSPACE;
         }
+        if (g_stamps && a.split <= 1 && (long long)(((M + 47) / 48 + 7) / 8 * 8) * ((H + 63) / 64) * 16 <= g_stamp_words) a.stamps = g_stamps;   // (bound: the smallest tile)
         rc = prof_open(U_MAIN, s); if (rc) return rc;
         rc = main_forward(a, s); if (rc) return rc;
         rc = prof_close(U_MAIN, s); if (rc) return rc;
@@ -1784,6 +1787,12 @@ int ncx_profile_end(float* ms, int32_t* ids, int32_t cap) {
     free(g_prof.ev); free(g_prof.ids);
     g_prof.ev = nullptr; g_prof.ids = nullptr; g_prof.on = false; g_prof.mask = 0; g_prof.n = 0; g_prof.cap = 0;
     return n < cap ? n : cap;
+}
+
+int ncx_profile_stamps(unsigned long long* stamps, int64_t words) {
+    if ((stamps == nullptr) != (words == 0) || words < 0) return NCX_E_DIMS;
+    g_stamps = stamps; g_stamp_words = words;
+    return NCX_OK;
 }
 
 int ncx_wgmap_check(int32_t tiles_m, int32_t tiles_n, int32_t S) {

@@ -19,7 +19,7 @@ NCX_F_BF16 = 16       # BASELINE configs[4]: bf16 operands for the two dominant 
 EXPORTS = ("ncx_input_size", "ncx_workspace_bytes", "ncx_forward", "ncx_loss_rank", "ncx_backward", "ncx_backward_phase",
            "ncx_adam_step", "ncx_version", "ncx_profile_begin", "ncx_profile_end", "ncx_plan_query",
            "ncx_vqa_workspace_bytes", "ncx_vqa_forward", "ncx_knn_workspace_bytes", "ncx_knn", "ncx_ws_region", "ncx_wgmap_check",
-           "ncx_comm_unique_id", "ncx_comm_create", "ncx_comm_destroy", "ncx_allreduce", "ncx_train_tail")
+           "ncx_comm_unique_id", "ncx_comm_create", "ncx_comm_destroy", "ncx_allreduce", "ncx_train_tail", "ncx_profile_stamps")
 
 
 class NcxDims(C.Structure):
@@ -112,6 +112,8 @@ def lib():
     L.ncx_profile_begin.argtypes = [C.c_uint32, C.c_int32]
     L.ncx_profile_end.restype = C.c_int
     L.ncx_profile_end.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int32]
+    L.ncx_profile_stamps.restype = C.c_int
+    L.ncx_profile_stamps.argtypes = [C.c_void_p, C.c_int64]
     L.ncx_train_tail.restype = C.c_int
     L.ncx_train_tail.argtypes = [C.POINTER(NcxDims), C.POINTER(NcxParams), C.c_void_p, C.c_size_t] + [C.c_void_p] * 7 + [C.POINTER(NcxGrads), C.c_void_p]
     L.ncx_comm_unique_id.restype = C.c_int; L.ncx_comm_unique_id.argtypes = [C.c_void_p]
@@ -158,6 +160,14 @@ def profile_end(cap=4096):
     for i in range(n):
         out.setdefault(inv[ids[i]], []).append(float(ms[i]))
     return out
+
+
+def profile_stamps(buf=None):
+    """Arm (int64 device tensor, >= 16 words per workgroup of MAIN) or disarm (None) the in-kernel clock stamps of MAIN."""
+    if buf is None:
+        check(lib().ncx_profile_stamps(None, 0), "ncx_profile_stamps")
+    else:
+        check(lib().ncx_profile_stamps(C.c_void_p(buf.data_ptr()), buf.numel()), "ncx_profile_stamps")
 
 
 def plan_query(d, name):
