@@ -155,9 +155,9 @@ int ncx_backward(const ncx_dims* d, const ncx_inputs* in, const ncx_params* p,
  * both halves run in order on the same stream and workspace:
  *   phase 1 | 2:  1 = out.*, linear_2/3.*, linear_1.bias and the complete answer_embedding gradient;
  *                 2 = linear_1.weight.
- *   phase 3 | 4:  3 = everything except the answer_embedding gradient; it leaves dGt | dGgt (2 x [H, A] fp32, the
- *                 gradient w.r.t. W1[:, a_emb_other] . E^T and the scattered dSh) in the workspace region
- *                 ncx_ws_region(NCX_WS_DGT);  4 = answer_embedding gradient = dGt^T . W1ak + dGgt^T . W1agt.
+ *   phase 3 | 4:  3 = everything except the answer_embedding gradient; it leaves the block dGt | dGgt (the gradient
+ *                 w.r.t. W1[:, a_emb_other] . E^T and the scattered dSh; layout: see NCX_WS_DGT below) in the workspace
+ *                 region ncx_ws_region(NCX_WS_DGT);  4 = answer_embedding gradient = dGt^T . W1ak + dGgt^T . W1agt.
  *                 The embedding gradient is linear in that region, so a DP job sums the 4 MB region over ranks
  *                 between 3 and 4 instead of all-reducing the 19 MB [A, da] gradient (every rank then computes the
  *                 same, complete gradient).
@@ -169,7 +169,11 @@ int ncx_backward_phase(const ncx_dims* d, const ncx_inputs* in, const ncx_params
                        void* workspace, size_t workspace_bytes, const float* dscores,
                        const ncx_grads* g, int32_t phase, void* stream);
 
-/* Byte offset (from the 256-byte aligned workspace base) and size of a named workspace region. */
+/* Byte offset (from the 256-byte aligned workspace base) and size of a named workspace region.
+ * NCX_WS_DGT: the block the answer_embedding gradient is linear in, in the form the library's own phases produce and
+ * consume it -- fp32 path: dGt^T | dGgt^T, 2 x [A][pad4(H)] fp32 (reduction index contiguous: the embedding gradient runs
+ * in NT form; 4.1 MB at A = 2000, H = 256); bf16 variant: dGt | dGgt, 2 x [H][A] fp32.  A DP job sums exactly
+ * [offset, offset + bytes) over ranks between phase 5 (or 3) and phase 4; size 0 when the a_emb segment is lesioned. */
 #define NCX_WS_DGT 1
 #define NCX_WS_H1 2     /* diagnostics / tests: post-dropout activations of linear_1, [B*K, H] (valid after ncx_forward) */
 #define NCX_WS_DPRE1 3  /* diagnostics / tests: gradient of linear_1's pre-activations, [B*K, H] (valid after ncx_backward) */

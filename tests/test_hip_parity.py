@@ -354,6 +354,7 @@ def test_fused_adam_vs_oracle_and_torch():
         assert torch.allclose(P.cpu(), tp.detach(), rtol=2e-6, atol=1e-7)
 
 
+
 def test_one_train_step_matches_golden_adam():
     """G5: forward + loss + backward + Adam on the HIP path == the reference's optimizer.step()."""
     from neuralcx import ops
@@ -367,12 +368,18 @@ def test_one_train_step_matches_golden_adam():
         M = torch.zeros_like(P); V = torch.zeros_like(P)
         ops.adam_step(P, G, M, V, 1, lr=1e-4)
         ref = g["adam1/" + k].reshape(-1)
-        # Adam normalises by sqrt(v): the first step moves every entry by lr * sign(g), so a RELATIVE gradient error eps becomes a
-        # parameter error ~eps * lr.  The gradients agree to 1e-4 of the tensor's max (checked above): entries above 1e-2 of the
-        # max are within 1e-2 relative, i.e. 1e-6 here (lr = 1e-4); smaller entries may move by up to +-lr either way
-        big = np.abs(g["grad/" + k].reshape(-1)) > 1e-2 * np.abs(g["grad/" + k]).max()
-        assert np.abs(P.cpu().numpy() - ref)[big].max() <= 2e-6, k
-        assert np.abs(P.cpu().numpy() - ref).max() <= 2.01e-4, k
+        # Adam's first step is p - lr * f(g) with f(g) = g / (|g| + 1e-8): it normalises by sqrt(v), so what a gradient error does
+        # to the parameter depends on the entry's own size.  The gradients agree to tol = 1e-4 of the tensor's max (checked by
+        # the parity tests), so EVERY entry must lie within the image of [g - tol, g + tol] under the step, element by element
+        # (+ 2e-6 of fp32 rounding in p): entries well above tol are pinned to ~1e-6, only entries below tol (whose sign the
+        # tolerance does not determine) may move by up to 2 lr.
+        gr = g["grad/" + k].reshape(-1).astype(np.float64)
+        tol = grad_tol(k, gr)
+        f = lambda x: x / (np.abs(x) + 1e-8)
+        bound = 1e-4 * np.maximum(np.abs(f(gr + tol) - f(gr)), np.abs(f(gr - tol) - f(gr))) + 2e-6
+        err = np.abs(P.cpu().numpy().astype(np.float64) - ref)
+        assert (err <= bound).all(), (k, float((err - bound).max()))
+        assert bound[np.abs(gr) > 3 * tol].max(initial=0.0) <= 2.1e-6          # (the bound is tight wherever the sign is determined)
 
 
 def test_phased_backward_is_bit_identical():

@@ -48,7 +48,10 @@ def build_parser():
     p = argparse.ArgumentParser(description="Train/Evaluate NeuralCX counterexample models (MI355X HIP path)")
     p.add_argument("--path_opt", default=os.path.join(HERE, "options", "cx", "neuralcx_256_1_all.yaml"), type=str)
     p.add_argument("--vqa_model", default="mutan_noatt_train", type=str)
-    p.add_argument("--cx_model", default="NeuralModel", type=str, help="NeuralModel | RandomBaseline | DistanceBaseline | BlackBox")
+    # (the reference makes -cx required, counterexamples.py:44; here NeuralModel is the default and the flag spellings are kept)
+    p.add_argument("-cx", "--cx_model", default="NeuralModel", type=str, help="NeuralModel | RandomBaseline | DistanceBaseline | BlackBox")
+    p.add_argument("-lb", "--sb_lambda", type=float, help="semantic baseline lambda (counterexamples.py:49; no NeuralModel code path "
+                                                          "reads it, in the reference either: accepted and ignored with a warning)")
     p.add_argument("--pairwise", action="store_true")
     p.add_argument("-dev", "--dev_mode", action="store_true", help="small train/val subsets")
     p.add_argument("--pretrained_vqa", dest="pretrained_vqa", action="store_true")
@@ -61,7 +64,7 @@ def build_parser():
     p.add_argument("--resume", type=str, default=None, help="run name to resume")
     p.add_argument("--best", action="store_true", help="resume the best checkpoint")
     p.add_argument("-c", "--comment", type=str, default="")
-    p.add_argument("-p", "--print_freq", default=10, type=int)
+    p.add_argument("-p", "--print_freq", default=100, type=int)          # counterexamples.py:65
     p.add_argument("-v", "--eval_freq", default=-1, type=int)
     p.add_argument("-t", "--test", action="store_true", help="evaluate the best model on the full validation set")
     p.add_argument("--viz", action="store_true")
@@ -306,6 +309,9 @@ def main(argv=None):
     if args.cx_model not in ("NeuralModel", "RandomBaseline", "DistanceBaseline", "BlackBox"):
         raise SystemExit("--cx_model {}: only NeuralModel and the RandomBaseline / DistanceBaseline / BlackBox scorers are "
                          "provided (the reference's other models are outside the accelerated path)".format(args.cx_model))
+    if args.sb_lambda is not None:
+        print("warning: -lb/--sb_lambda {} is accepted for command-line compatibility and ignored (no {} code path reads it)".format(
+            args.sb_lambda, args.cx_model), file=sys.stderr)
     if args.pairwise or args.viz:
         raise SystemExit("--pairwise / --viz are outside the accelerated path (SURVEY 8: out of scope)")
     r = Runner(args, options)

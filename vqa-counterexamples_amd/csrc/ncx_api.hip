@@ -1322,6 +1322,13 @@ int ncx_loss_rank(const float* scores, const int32_t* gt, int32_t B, int32_t K, 
     return NCX_OK;
 }
 
+}  // extern "C"
+// The answer-embedding gradient runs in NT form (operands dGt^T | dGgt^T, csrc/ncx_main.h) for the fp32 path with the a_emb
+// segment on.  ONE predicate: ncx_train_tail and backward_impl fill the block in that form, ncx_ws_region names it.
+static inline bool emb_nt_form(const ncx_dims& d) {
+    return (d.flags & NCX_F_A_EMB) && !(d.flags & NCX_F_BF16) && !ncx::hook_env("NCX_NO_EMB_NT");
+}
+extern "C" {
 int ncx_train_tail(const ncx_dims* dp, const ncx_params* p, void* workspace, size_t workspace_bytes, const int32_t* gt,
                    float* scores, float* loss_rows, float* loss, float* dscores, int32_t* rank, int32_t* hits,
                    const ncx_grads* g, void* stream_) {
@@ -1338,7 +1345,7 @@ int ncx_train_tail(const ncx_dims* dp, const ncx_params* p, void* workspace, siz
     char* ws = (char*)workspace;
     const int H = d.H;
     const bool aemb = d.flags & NCX_F_A_EMB;
-    const bool emb_nt = aemb && !(d.flags & NCX_F_BF16) && !hook_env("NCX_NO_EMB_NT");
+    const bool emb_nt = emb_nt_form(d);
     const int Hp4 = pad_to(H, 4);
     float* dagtT = (float*)(ws + w.dgtT) + (size_t)d.A * Hp4;
     float* dagt = (float*)(ws + w.dagt);
@@ -1410,7 +1417,7 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
     const float* mx = (const float*)(ws + w.mx); const float* inv = (const float*)(ws + w.inv);
     const float* misc = (const float*)(ws + w.misc); const float* gt = (const float*)(ws + w.gt);
     float* dsh = (float*)(ws + w.dsh); float* dgt = (float*)(ws + w.dgt); float* dagt = (float*)(ws + w.dagt);
-    const bool emb_nt = aemb && !(d.flags & NCX_F_BF16) && !hook_env("NCX_NO_EMB_NT");   // answer-embedding gradient in NT form on the fused forward kernel
+    const bool emb_nt = emb_nt_form(d);   // answer-embedding gradient in NT form on the fused forward kernel
     const int Hp4 = pad_to(H, 4), Hp32 = pad_to(H, 32);
     float* dgtT = (float*)(ws + w.dgtT); float* dagtT = dgtT + (size_t)d.A * Hp4;
     float* w1akT = (float*)(ws + w.w1aT); float* w1agtT = w1akT + (size_t)d.da * Hp32;
@@ -1634,8 +1641,9 @@ int ncx_ws_region(const ncx_dims* dp, int32_t which, size_t* offset, size_t* byt
         *bytes = (size_t)dp->B * dp->K * dp->H * 4;
         return NCX_OK;
     }
-    if (dp->flags & NCX_F_BF16) { *offset = w.dgt; *bytes = (dp->flags & NCX_F_A_EMB) ? (size_t)2 * dp->H * dp->A * 4 : 0; }
-    else { *offset = w.dgtT; *bytes = (dp->flags & NCX_F_A_EMB) ? (size_t)2 * dp->A * pad_to(dp->H, 4) * 4 : 0; }   // dGt^T | dGgt^T
+    // the block a DP job sums between phases 5 / 3 and 4 is the one backward_impl fills: the same predicate decides its form
+    if (!emb_nt_form(*dp)) { *offset = w.dgt; *bytes = (dp->flags & NCX_F_A_EMB) ? (size_t)2 * dp->H * dp->A * 4 : 0; }               // dGt | dGgt, [H][A] x 2
+    else { *offset = w.dgtT; *bytes = (size_t)2 * dp->A * pad_to(dp->H, 4) * 4; }                                                     // dGt^T | dGgt^T, [A][pad4(H)] x 2
     return NCX_OK;
 }
 

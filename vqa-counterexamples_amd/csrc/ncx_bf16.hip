@@ -302,11 +302,8 @@ template <int BM, int BN>
 static int launch_bf16_nt(const u16* xc, int M, const u16* wc, int N, int kc, const EpiArgs& epi, float* out, hipStream_t s,
                           long long ldo = 0) {
     const int lds = 2 * (BM + BN) * NT_PITCH;
-    static bool attr = false;
-    if (!attr) {
-        NCX_HIP_TRY(hipFuncSetAttribute((const void*)gemm_bf16_nt_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = true;
-    }
+    static DevMask attr{0};
+    NCX_HIP_TRY(set_max_lds_once(attr, (const void*)gemm_bf16_nt_kernel<BM, BN>, lds));
     const int wgs = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     hipLaunchKernelGGL((gemm_bf16_nt_kernel<BM, BN>), dim3(wgs), dim3(256), lds, s, xc, M, wc, N, kc, out, ldo ? ldo : (long long)N, epi);
     NCX_HIP_TRY(hipGetLastError());
@@ -346,11 +343,8 @@ int bf16_dw1c(const ncx_dims& d, const float* dpre, u16* dpre_bf, const u16* xc,
     }
     constexpr int BM = 128, BN = 128;
     const int lds = 4 * 64 * TN_PITCH;
-    static bool attr = false;
-    if (!attr) {
-        NCX_HIP_TRY(hipFuncSetAttribute((const void*)gemm_bf16_tn_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = true;
-    }
+    static DevMask attr{0};
+    NCX_HIP_TRY(set_max_lds_once(attr, (const void*)gemm_bf16_tn_kernel<BM, BN>, lds));
     const int chunk = (int)(((long long)(M + BF16_SPLIT - 1) / BF16_SPLIT + 63) / 64 * 64);
     const int nz = (M + chunk - 1) / chunk;
     const int tiles_m = Hp / BM, tiles_n = cc.kc / BN;
@@ -435,11 +429,8 @@ int bf16_de(const ncx_dims& d, const Bf16Emb& m, const float* dgt_dagt, float* g
     int rc = pack2d(dgt_dagt, d.A, 2 * d.H, d.A, m.dg_bf, 2 * d.H, m.Ap, s); if (rc) return rc;
     constexpr int BM = 128, BN = 128;
     const int lds = 4 * 64 * TN_PITCH;
-    static bool attr = false;
-    if (!attr) {
-        NCX_HIP_TRY(hipFuncSetAttribute((const void*)gemm_bf16_tn_kernel<BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = true;
-    }
+    static DevMask attr{0};
+    NCX_HIP_TRY(set_max_lds_once(attr, (const void*)gemm_bf16_tn_kernel<BM, BN>, lds));
     const int rows = 2 * d.H, tiles_m = m.Ap / BM, tiles_n = m.dap / BN;
     hipLaunchKernelGGL((gemm_bf16_tn_kernel<BM, BN>), dim3(tiles_m * tiles_n), dim3(256), lds, s, (const u16*)m.dg_bf, m.Ap,
                        (const u16*)m.w1a_bf, m.dap, rows, (rows + 63) / 64 * 64, tiles_m, 1, g_E, d.A, d.da);

@@ -41,3 +41,21 @@ namespace ncx {
 static inline bool experiment_hooks_on() { const char* e = getenv("NCX_EXPERIMENT"); return e && e[0] == '1'; }
 static inline const char* hook_env(const char* name) { return experiment_hooks_on() ? getenv(name) : nullptr; }
 }  // namespace ncx
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE property of a kernel: one bit per device (hipGetDevice) in an
+// atomic mask per kernel instantiation, so a host that drives several GPUs from one process (or several host threads)
+// opts every device in exactly once.
+#include <atomic>
+namespace ncx {
+typedef std::atomic<unsigned long long> DevMask;
+static inline hipError_t set_max_lds_once(DevMask& done, const void* fn, int lds_bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+}  // namespace ncx

@@ -293,8 +293,8 @@ int dw_km(const ncx_dims& d, const float* dpre, const float* feats, const int* i
         constexpr bool EDGE = decltype(edge_c)::value;
         constexpr int QA = BM / 4, NA = (R * QA + 255) / 256, KA = NA * 256 / QA, KB = (R * 16 + 255) / 256 * 16;
         const int lds = 2 * (KA * (BM + 16) + KB * KM_PB) * 4;
-        static bool attr = false;
-        if (!attr) { NCX_HIP_TRY(hipFuncSetAttribute((const void*)k_dw_km<R, BM, OCC, EDGE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = true; }
+        static DevMask attr{0};
+        NCX_HIP_TRY(set_max_lds_once(attr, (const void*)k_dw_km<R, BM, OCC, EDGE>, lds));
         hipLaunchKernelGGL((k_dw_km<R, BM, OCC, EDGE>), dim3(tiles_m * tiles_n * S), dim3(256), lds, s, dpre, d.H, feats, d.dv, idx_k, idx_o, d.B, d.K,
                            chunk, tiles_m, S, slab);
         return (int)hipGetLastError();

@@ -1020,12 +1020,10 @@ static inline hipError_t launch_seg_gemm(GemmArgs& args, hipStream_t stream) {
     bool any_split = false;
     const long long wgs = gemm_layout(args, BM, BN, &any_split);
     if (wgs == 0) return hipSuccess;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)seg_gemm_kernel<BM, BN, A_COLK, B_COLK, FOLD>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+    static DevMask attr_set{0};
+    {
+        hipError_t e = set_max_lds_once(attr_set, (const void*)seg_gemm_kernel<BM, BN, A_COLK, B_COLK, FOLD>, Cfg::LDS_BYTES);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     args.total_wgs = (int)wgs;
     long long grid = wgs;

@@ -731,8 +731,8 @@ template <int K0, int... REST> struct FirstKind { static constexpr int value = K
 template <class CFG, bool DIST, int... KINDS>
 static inline int launch_main_fwd_seq(MainArgs& a, hipStream_t s) {
     constexpr int lds = FirstKind<KINDS...>::value == MK_VFOLD ? (CFG::LDS_FOLD > CFG::LDS ? CFG::LDS_FOLD : CFG::LDS) : CFG::LDS;
-    static bool attr = false;
-    if (!attr) { NCX_HIP_TRY(hipFuncSetAttribute((const void*)k_main_fwd<CFG, DIST, KINDS...>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); attr = true; }
+    static DevMask attr{0};
+    NCX_HIP_TRY(set_max_lds_once(attr, (const void*)k_main_fwd<CFG, DIST, KINDS...>, lds));
     const int tiles_m = (a.M + CFG::BM - 1) / CFG::BM, tiles_n = (a.N + CFG::BN - 1) / CFG::BN;
     const int S = a.split > 1 ? a.split : 1;
     const int grid = ((tiles_m * S + 7) / 8) * 8 * tiles_n;

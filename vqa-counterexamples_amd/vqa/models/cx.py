@@ -179,6 +179,21 @@ class NeuralModel(CXModelBase):
         call = dict(dims=d, batch=batch, names=names, pool=self._pool, record=record)      # per-call snapshot (re-entrant: see ops.WorkspacePool)
         return ops.NeuralCXFunction.apply(call, *tensors)
 
+    _aid_host, _aid_event, _aid_pending = None, None, False
+
+    def check_answer_ids(self, wait=True):
+        """Raises IndexError if the previous forward saw an answer id outside [0, ans_size) (what nn.Embedding raises at
+        cx.py:280).  wait=False: only if the flag's copy has already landed (never blocks the host)."""
+        if not self._aid_pending:
+            return
+        if self._aid_event is not None:
+            if not wait and not self._aid_event.query():
+                return
+            self._aid_event.synchronize()
+        self._aid_pending = False
+        if bool(self._aid_host[0]):
+            raise IndexError("answer_aids outside [0, %d) in the previous forward" % self.ans_size)
+
     def forward(self, image_features, question_wids, answer_aids):
         spec = self.model_spec
         B = image_features.size(0)
@@ -202,11 +217,20 @@ class NeuralModel(CXModelBase):
         if not spec.get("v_rank", True):                                        # cx.py:306-307
             extra["v_rank"] = torch.rand(B, K, K, device=dev)
         if spec.get("a_emb", True) and answer_aids.numel():
-            # nn.Embedding raises on a bad index (cx.py:280); the kernels gather / scatter embedding rows by it, so check
-            # here (one host sync; the reference's loop syncs every step anyway: recallAtK, counterexamples.py:333)
-            lo, hi = int(answer_aids.min()), int(answer_aids.max())
-            if lo < 0 or hi >= self.ans_size:
-                raise IndexError("answer_aids outside [0, %d): [%d, %d]" % (self.ans_size, lo, hi))
+            # nn.Embedding raises on a bad index (cx.py:280); the kernels gather / scatter embedding rows by it.  No host
+            # sync per forward: the ids are clamped for the kernels, the verdict goes to a device flag whose copy to pinned
+            # host memory is read at the NEXT forward (long complete by then) or by check_answer_ids() -- the error of
+            # step n surfaces at step n + 1 at the latest, before its scores can have been used for a second update.
+            self.check_answer_ids(wait=False)
+            bad = ((answer_aids < 0) | (answer_aids >= self.ans_size)).any()
+            answer_aids = answer_aids.clamp(0, self.ans_size - 1)
+            if self._aid_host is None:
+                self._aid_host = torch.zeros(1, dtype=torch.bool).pin_memory() if dev.type == "cuda" else torch.zeros(1, dtype=torch.bool)
+            self._aid_host.copy_(bad.view(1), non_blocking=True)
+            if dev.type == "cuda":
+                self._aid_event = torch.cuda.Event()
+                self._aid_event.record(torch.cuda.current_stream(dev))
+            self._aid_pending = True
         batch = ops.Batch.from_dense(image_features.float(), q_emb.float(), z_orig.float(), z_knns.float(),
                                      a_knns.float(), answer_aids, **extra)
         return self.score_batch(batch)
