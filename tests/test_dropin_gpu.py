@@ -145,62 +145,105 @@ def test_engine_training_matches_oracle_training():
     assert abs(float(ev["loss"]) - l_held) <= 1e-3
 
 
-def test_full_width_training_run_matches_reference_faithful_cpu_training():
-    """north_star: "Recall@5 matching the reference to +-0.1 on identical synthetic data".  Full model widths (2048-d
-    features, 2400-d question / answer embeddings, 2000 answers, H=256, L=1, dropout 0.25), 40 Adam steps of batch 32
-    (BASELINE configs[0]'s batch) on planted synthetic triplets: the HIP engine and the CPU oracle's reference-faithful
-    training (24-iteration cat + Linear loop, autograd, Adam at the reference's lr 1e-4, options/cx/*.yaml:61; shared
-    counter-based dropout masks) must produce the same loss curve and the same Recall@1 / Recall@5 on 128 held-out triplets.
+def test_full_width_training_against_the_fp64_referee_and_heldout_recall():
+    """north_star: "Recall@5 matching the reference to +-0.1 on identical synthetic data".  Full model widths (2048-d features,
+    2400-d question / answer embeddings, 2000 answers, H=256, L=1, dropout 0.25), 200 Adam steps of batch 32 (BASELINE
+    configs[0]'s batch) at the reference's lr 1e-4 (options/cx/*.yaml:61) on planted synthetic triplets, then 4 096 held-out
+    triplets.  THREE trainings on identical batches with identical (counter-based) dropout masks: the HIP engine, the
+    reference-faithful fp32 CPU oracle (the PyTorch CPU path: 24-iteration cat + Linear loop, autograd, Adam), and the
+    same oracle in fp64 as REFEREE.
 
-    What "the same" can mean for two fp32 implementations: with identical weights the losses agree to 1e-5 (step 0).  After
-    that the curves separate through ONE mechanism (tools/grad_check.py shows it on this very data): a ReLU input within
-    rounding of zero switches its unit in one implementation and not in the other -- at batch 32 a single unit is ~1 % of
-    some gradient entries -- and Adam's normalised update amplifies whatever differs.  Two CPU BLAS builds separate the same
-    way.  Bounds: <= 2e-3 per step (0.06 % of the loss), held-out loss within 2e-3, held-out Recall@1 / @5 identical on every
-    triplet whose ground truth is not within 5e-3 of the rank boundary (totals within 3 of 128)."""
-    from neuralcx import ops
+    What the referee shows (tools/referee.py prints the full table): two correct fp32 implementations of this
+    training do not stay together -- a ReLU input within rounding of zero switches its unit on one side only, Adam's
+    normalised update amplifies whatever differs, and after ~100 steps the trajectories are decorrelated at the 1e-2 level of
+    the scores.  The fp32 CPU reference itself separates from fp64 by 1e-3 in the loss within 40 steps; the HIP path stays
+    within 5e-5 of fp64 over the same steps (its gradients are 1e-3..1e-4 times closer to fp64 than torch's fp32 autograd).
+    So the checks are:
+      * steps 0 .. 39, against the referee: |loss_HIP - loss_f64| <= 2e-4 (round 1's bound; step 0: <= 1e-5), and the HIP
+        run is closer to the referee than the fp32 reference is (running maxima);
+      * after 40 steps, 4 096 held-out triplets HIP vs referee: Recall@1 / @5 totals within 0.1 pt, and every triplet
+        whose ground truth is further than 1e-3 from its rank boundary classified identically (count of excluded
+        near-ties reported, <= 1 %);
+      * after 200 steps (Recall@5 > 0.40, chance 0.208) the three trajectories are decorrelated: the fp32 reference and the
+        HIP run each classify ~60 of the 4 096 triplets differently from the referee at k = 5 (measured: 61 and 61; 25 and 18
+        at k = 1), i.e. the REFERENCE's Recall@5 is only defined to ~+-0.2 pt at this horizon (0.07 .. 0.22 pt observed on two
+        held-out sets).  Checks: the HIP run disagrees with the referee on no more triplets than the fp32 reference does
+        (x 1.5 + 10), and its total differs from the referee's by no more than a symmetric random walk over the disagreeing
+        triplets allows (3 sigma = 3 sqrt(n)): no systematic bias.  Totals are printed in percent."""
     from neuralcx.engine import NeuralCXEngine
     from neuralcx.synth import SyntheticCX
     d = orc.Dims()                                           # K=24, dv=2048, dq=2400, dz=360, da=2400, A=2000, H=256, L=1
-    B, steps, p_drop, lr = 32, 40, 0.25, 1e-4
-    data = SyntheticCX(n_triplets=B * steps + 128, n_img=1024, seed=77, device=DEV)
+    B, steps, p_drop, lr, HELD = 32, 200, 0.25, 1e-4, 4096
+    data = SyntheticCX(n_triplets=B * steps + HELD, n_img=1024, seed=77, device=DEV)
     eng = NeuralCXEngine(H=d.H, L=d.L, drop_p=p_drop, lr=lr, device=DEV)
     params = orc.init_params(d, seed=42)
     eng.load_state(params)
-    st = orc.AdamState()
-    cur = {k: v.clone() for k, v in params.items()}
     feats_cpu = data.feats.cpu()
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
 
-    def cpu_batch(b, gt):
-        return dict(image_features=feats_cpu[b.img_idx.cpu().long()], q_emb=b.q_emb.cpu(), z_orig=b.z_orig.cpu(), z_knns=b.z_knns.cpu(),
-                    a_knns=b.a_knns.cpu(), answer_aids=b.answer_aids.cpu().long(), gt=gt.cpu().long())
-    worst = 0.0
+    def cpu_batch(b, gt, dt):
+        f = lambda t: t.cpu().to(dt)
+        return dict(image_features=feats_cpu[b.img_idx.cpu().long()].to(dt), q_emb=f(b.q_emb), z_orig=f(b.z_orig), z_knns=f(b.z_knns),
+                    a_knns=f(b.a_knns), answer_aids=b.answer_aids.cpu().long(), gt=gt.cpu().long())
+    sides = {"o32": torch.float32, "f64": torch.float64}
+    cur = {n: {k: v.to(dt) for k, v in params.items()} for n, dt in sides.items()}
+    st = {n: orc.AdamState() for n in sides}
+
+    def heldout(names):
+        """-> {side: rank-of-gt [HELD]}, f64 scores, gt"""
+        R = {n: [] for n in names + ["hip"]}
+        s64, gts = [], []
+        for lo in range(0, HELD, 512):
+            hb, hgt = data.batch(torch.arange(B * steps + lo, B * steps + lo + 512, device=DEV), first_id=B * steps + lo)
+            R["hip"].append(eng.eval_step(hb, hgt)["rank"].cpu().numpy())
+            gts.append(hgt.cpu().numpy())
+            for n in names:
+                hc = cpu_batch(hb, hgt, sides[n])
+                with torch.no_grad():
+                    sc = orc.forward_faithful(cur[n], d, hc["image_features"], hc["q_emb"], hc["z_orig"], hc["z_knns"], hc["a_knns"], hc["answer_aids"])
+                R[n].append(orc.rank_of_gt(sc.numpy(), hc["gt"].numpy()))
+                if n == "f64":
+                    s64.append(sc.numpy())
+        return {n: np.concatenate(v) for n, v in R.items()}, (np.concatenate(s64) if s64 else None), np.concatenate(gts)
+
+    worst = {"hip": 0.0, "o32": 0.0}
     for s in range(steps):
         b, gt = data.batch(torch.arange(s * B, (s + 1) * B, device=DEV), first_id=s * B)
         r = eng.train_step(b, gt)
         seed = (eng.seed << 32) ^ eng.step_count
-        masks = [orc.dropout_keep_mask(seed, 1, B * d.K, d.H, p_drop)]
-        cur, _, l_ref, _ = orc.train_step(cur, d, cpu_batch(b, gt), st, lr=lr, drop_p=p_drop, keep_masks=masks)
-        worst = max(worst, abs(float(r["loss"]) - float(l_ref)))
-        assert worst <= (1e-5 if s == 0 else 2e-3), (s, float(r["loss"]), float(l_ref))
-    hb, hgt = data.batch(torch.arange(B * steps, B * steps + 128, device=DEV), first_id=B * steps)
-    ev = eng.eval_step(hb, hgt)
-    hc = cpu_batch(hb, hgt)
-    s_ref = orc.forward_faithful(cur, d, hc["image_features"], hc["q_emb"], hc["z_orig"], hc["z_knns"], hc["a_knns"], hc["answer_aids"])
-    # held-out Recall@1 / @5: the two weight sets differ by ~1e-3 after 40 steps, i.e. the scores by ~1e-3, so a triplet whose
-    # ground truth sits within 5e-3 of its rank-1 / rank-5 boundary can land on either side.  Every other triplet must agree
-    # EXACTLY; the totals within 3 of 128.
-    sr = s_ref.numpy(); gtn = hc["gt"].numpy()
-    sg = sr[np.arange(128), gtn]
-    srt = -np.sort(-sr, axis=1)
-    rank_hip = ev["rank"].cpu().numpy(); rank_ref = orc.rank_of_gt(sr, gtn)
-    for k, i in ((1, 0), (5, 1)):
-        # boundary of "gt in top k": the k-th and (k+1)-th best scores
-        near = (np.abs(sg - srt[:, k - 1]) < 5e-3) & (np.abs(sg - srt[:, k]) < 5e-3) | ((np.abs(sg - srt[:, k]) < 5e-3) & (rank_ref < k)) | ((np.abs(sg - srt[:, k - 1]) < 5e-3) & (rank_ref >= k))
-        assert ((rank_hip < k) == (rank_ref < k))[~near].all(), k
-        n_hip, n_ref = int(ev["hits"][i]), int((rank_ref < k).sum())
-        assert abs(n_hip - n_ref) <= 3, (k, n_hip, n_ref)
-    assert abs(float(ev["loss"]) - float(orc.ranking_loss(s_ref, hc["gt"]))) <= 2e-3
+        mask = orc.dropout_keep_mask(seed, 1, B * d.K, d.H, p_drop)
+        loss = {}
+        for n, dt in sides.items():
+            cur[n], _, l, _ = orc.train_step(cur[n], d, cpu_batch(b, gt, dt), st[n], lr=lr, drop_p=p_drop, keep_masks=[mask.to(dt)])
+            loss[n] = float(l)
+        if s < 40:
+            worst["hip"] = max(worst["hip"], abs(float(r["loss"]) - loss["f64"]))
+            worst["o32"] = max(worst["o32"], abs(loss["o32"] - loss["f64"]))
+            assert worst["hip"] <= (1e-5 if s == 0 else 2e-4), (s, float(r["loss"]), loss["f64"])
+        if s == 39:
+            # the first 40 steps: HIP no further from the referee than the fp32 reference (+ fp32 resolution of the loss itself)
+            assert worst["hip"] <= worst["o32"] + 2e-6, worst
+            R, s64, gtn = heldout(["f64"])
+            sg = s64[np.arange(HELD), gtn]
+            srt = -np.sort(-s64, axis=1)
+            for k in (1, 5):
+                margin = np.minimum(np.abs(sg - srt[:, k - 1]) + (R["f64"] < k) * 1e9, np.abs(sg - srt[:, k]) + (R["f64"] >= k) * 1e9)
+                near = margin < 1e-3                                   # gt within 1e-3 of the side of the boundary it would cross
+                assert ((R["hip"] < k) == (R["f64"] < k))[~near].all(), k
+                assert near.mean() <= 0.01, (k, int(near.sum()))
+                n_hip, n_ref = int((R["hip"] < k).sum()), int((R["f64"] < k).sum())
+                assert abs(n_hip - n_ref) <= 0.001 * HELD, (k, n_hip, n_ref)
+                print("after 40 steps: Recall@%d HIP %d / f64 %d of %d (near-ties excluded from the per-triplet check: %d)" % (k, n_hip, n_ref, HELD, int(near.sum())))
+    R, _, _ = heldout(["o32", "f64"])
+    for k in (1, 5):
+        rec = {n: 100.0 * float((R[n] < k).mean()) for n in R}
+        print("after %d steps: Recall@%d  HIP %.3f  fp32 CPU reference %.3f  fp64 referee %.3f  (%%; disagreeing triplets HIP/f64 %d, o32/f64 %d)"
+              % (steps, k, rec["hip"], rec["o32"], rec["f64"], int(((R["hip"] < k) != (R["f64"] < k)).sum()), int(((R["o32"] < k) != (R["f64"] < k)).sum())))
+        dis_h, dis_o = int(((R["hip"] < k) != (R["f64"] < k)).sum()), int(((R["o32"] < k) != (R["f64"] < k)).sum())
+        assert dis_h <= 1.5 * dis_o + 10, (k, dis_h, dis_o)
+        assert abs(int((R["hip"] < k).sum()) - int((R["f64"] < k).sum())) <= 3.0 * np.sqrt(max(dis_h, dis_o, 1)), (k, rec, dis_h, dis_o)
+        if k == 5:
+            assert rec["hip"] > 40.0, rec                                # learned (chance 20.8 %)
 
 
 def test_cli_synthetic_smoke(tmp_path, capsys):
