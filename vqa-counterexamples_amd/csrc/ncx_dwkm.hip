@@ -104,16 +104,57 @@ __global__ __launch_bounds__(256, OCC) void k_dw_km(const float* __restrict__ dp
         }
     };
     constexpr int nk4 = K / 4;
-    // One reduction step = one triplet.  The operand fragments of sub-step s4+2 are read from LDS under the MFMAs of sub-step
-    // s4 (read just before use, each group of 4 MFMAs waited ~100 cycles for its ds_read: the pipes ran at 64 %), and the first
-    // two sub-steps also carry the address arithmetic and global loads of the triplet two steps ahead.
+    // One reduction step = one triplet, software-pipelined over THREE triplets (round 3): under the MFMAs of triplet b run
+    //   * the fold of triplet b-1 (its T_b and v_o slice are carried in registers: tp / vp) -- the fold used to run after the last
+    //     MFMA of its own step with the matrix pipe idle (timing ablation: 9 us of the kernel),
+    //   * the LDS stores of triplet b+1's tile into the other buffer (they used to sit between the step and its barrier: 20 us),
+    //   * the global loads of triplet b+2 and the gather indices of triplet b+4.
+    // The operand fragments of sub-step s4+2 are read from LDS under the MFMAs of sub-step s4 (read just before use, each group
+    // of 4 MFMAs waited ~100 cycles for its ds_read).  Same arithmetic in the same order as before: results bit-identical.
     auto read_frag = [&](const float* pa, const float* pb, int s4, float (&af)[WM], float (&bf)[WN]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < WM; ++i) af[i] = pa[s4 * 4 * KM_PA + 16 * i];
 #pragma unroll
         for (int j = 0; j < WN; ++j) bf[j] = pb[s4 * 4 * KM_PB + 16 * j];
     };
-    auto step = [&](f32x4 (&ra)[NA], f32x4 (&rb)[NB], Ix& ix, int bnext, int buf, float keep) __attribute__((always_inline)) -> float {
+    f32x4 tp[WM][WN];                                    // T of the previous triplet (not folded yet)
+    float vp[WN], keep_p = 0.f;                          // its v_o slice (times its weight) and its weight
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) tp[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < WN; ++j) vp[j] = 0.f;
+    auto fold_block = [&](int blk) __attribute__((always_inline)) {          // block blk = (i, j) of the previous triplet's T
+        const int i = blk / WN, j = blk % WN;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (ABL == 4) { acc_k[i][j][q] += tp[i][j][q]; continue; }
+            acc_k[i][j][q] = __builtin_fmaf(tp[i][j][q], keep_p, acc_k[i][j][q]);
+            acc_m[i][j][q] = __builtin_fmaf(tp[i][j][q], vp[j], acc_m[i][j][q]);
+        }
+    };
+    // stash item it (0 .. NA + NB - 1) of the NEXT triplet's register set into LDS buffer `buf`
+    auto stash_item = [&](const f32x4 (&ra)[NA], const f32x4 (&rb)[NB], int buf, int it) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (i != it) continue;
+            const int f = tid + 256 * i;
+            const f32x4 v = EDGE ? fix_window(ra[i], m0 + 4 * (f % QA), H) : ra[i];
+            *(f32x4*)(lds_a + buf * a_elems + (f / QA) * KM_PA + 4 * (f % QA)) = v;      // (rows >= K: copies of row K-1, never read)
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (i + NA != it) continue;
+            const int f = tid + 256 * i;
+            const f32x4 v = EDGE ? fix_window(rb[i], n0 + 4 * (f & 15), dv) : rb[i];
+            *(f32x4*)(lds_b + buf * b_elems + (f >> 4) * KM_PB + 4 * (f & 15)) = v;
+        }
+    };
+    constexpr int NBLK = WM * WN, NIT = NA + NB;
+    // (rn, rbn): register set of triplet b+1, stashed into LDS[buf ^ 1] here; (ri, rbi): the set the loads of triplet b+2 go to
+    // -- the set triplet b came from, stashed during the previous step.  Returns the weight of triplet b+2.
+    auto step = [&](f32x4 (&ri)[NA], f32x4 (&rbi)[NB], const f32x4 (&rn)[NA], const f32x4 (&rbn)[NB], Ix& ix, int bnext, int buf, float keep) __attribute__((always_inline)) -> float {
         const float* pa = lds_a + buf * a_elems + lk * KM_PA + wm0 + li;
         const float* pb = lds_b + buf * b_elems + lk * KM_PB + wn0 + li;
         f32x4 tt[WM][WN];
@@ -131,9 +172,17 @@ __global__ __launch_bounds__(256, OCC) void k_dw_km(const float* __restrict__ dp
 #pragma unroll
         for (int s4 = 0; s4 < nk4; ++s4) {               // (one scheduling region per sub-step: reads cannot sink to their use)
             if (s4 + 2 < nk4) read_frag(pa, pb, s4 + 2, af[s4 + 2], bf[s4 + 2]);
-            if (s4 == 0 && ABL != 2) knext = issue(ra, rb, ix, bnext);
+            if (s4 == 0 && ABL != 2) knext = issue(ri, rbi, ix, bnext);
             if (s4 == 1 && ABL != 2) issue_idx(ix, bnext + 2);
             if (ABL == 2) knext = 1.f;
+            // the previous triplet's fold and the next triplet's LDS stores, spread over the sub-steps (the stores from sub-step 1
+            // on: their loads were issued a whole step ago)
+#pragma unroll
+            for (int blk = 0; blk < NBLK; ++blk) if (blk * nk4 / NBLK == s4) fold_block(blk);
+            if (ABL != 3 && s4 >= 1) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) if (it * (nk4 - 1) / NIT == s4 - 1) stash_item(rn, rbn, buf ^ 1, it);
+            }
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -141,17 +190,12 @@ __global__ __launch_bounds__(256, OCC) void k_dw_km(const float* __restrict__ dp
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int j = 0; j < WN; ++j) vm[j] *= keep;
-#pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int j = 0; j < WN; ++j)
+            for (int j = 0; j < WN; ++j) tp[i][j] = tt[i][j];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (ABL == 4) { acc_k[i][j][q] += tt[i][j][q]; continue; }
-                    acc_k[i][j][q] = __builtin_fmaf(tt[i][j][q], keep, acc_k[i][j][q]);
-                    acc_m[i][j][q] = __builtin_fmaf(tt[i][j][q], vm[j], acc_m[i][j][q]);
-                }
+        for (int j = 0; j < WN; ++j) vp[j] = vm[j] * keep;
+        keep_p = keep;
         return knext;
     };
 
@@ -165,19 +209,17 @@ __global__ __launch_bounds__(256, OCC) void k_dw_km(const float* __restrict__ dp
     float kc = k0;                                       // weight of the triplet whose tile sits in LDS[0]
     __syncthreads();
     for (int b = b0; b < b1; b += 2) {
-        // LDS[0] = triplet b (kc); set 1 = triplet b+1 in flight; ix0 / ix1 = indices of triplets b+2 / b+3
-        k0 = step(ra0, rb0, ix0, b + 2, 0, kc);
-        __builtin_amdgcn_sched_barrier(0);               // (the compiler otherwise hoists the stash -- and its wait for ALL loads -- above the issue)
-        if (ABL != 3) stash(ra1, rb1, 1);
+        // LDS[0] = triplet b (kc); set 1 = triplet b+1 (landing; stored to LDS[1] inside the step); ix0 / ix1 = indices of triplets b+2 / b+3
+        k0 = step(ra0, rb0, ra1, rb1, ix0, b + 2, 0, kc);
         const float kn = k1;
         if (ABL != 1) __syncthreads();
-        // LDS[1] = triplet b+1 (kn); set 0 = triplet b+2 in flight
-        k1 = step(ra1, rb1, ix1, b + 3, 1, kn);
-        __builtin_amdgcn_sched_barrier(0);
-        if (ABL != 3) stash(ra0, rb0, 0);
+        // LDS[1] = triplet b+1 (kn); set 0 = triplet b+2 (landing; stored to LDS[0] inside the step)
+        k1 = step(ra1, rb1, ra0, rb0, ix1, b + 3, 1, kn);
         kc = k0;
         if (ABL != 1) __syncthreads();
     }
+#pragma unroll
+    for (int blk = 0; blk < NBLK; ++blk) fold_block(blk);      // the last triplet's fold
     float* dk = slab + ((long long)z * 2 + 0) * H * dv;
     float* dm = slab + ((long long)z * 2 + 1) * H * dv;
 #pragma unroll
