@@ -133,6 +133,9 @@ __global__ __launch_bounds__(256, OCC) void k_dw_km(const float* __restrict__ dp
             acc_k[i][j][q] = __builtin_fmaf(tp[i][j][q], keep_p, acc_k[i][j][q]);
             acc_m[i][j][q] = __builtin_fmaf(tp[i][j][q], vp[j], acc_m[i][j][q]);
         }
+        // pin the fold to the sub-step it was placed in (the optimiser otherwise sinks a whole step's fold down to its only user,
+        // the next step's fold: one step with 128 vector instructions under its MFMAs, the other with none)
+        asm volatile("" : "+v"(acc_k[i][j]), "+v"(acc_m[i][j]));
     };
     // stash item it (0 .. NA + NB - 1) of the NEXT triplet's register set into LDS buffer `buf`
     auto stash_item = [&](const f32x4 (&ra)[NA], const f32x4 (&rb)[NB], int buf, int it) __attribute__((always_inline)) {

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libneuralcx_hip.so")
+LIB_PATH = os.environ.get("NCX_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libneuralcx_hip.so")   # (NCX_LIB: A/B builds, tools/)
 
 NCX_F_V_MULT, NCX_F_V_DIST, NCX_F_V_RANK, NCX_F_A_EMB = 1, 2, 4, 8
 NCX_F_ALL = 15
