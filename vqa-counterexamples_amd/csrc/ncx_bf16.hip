@@ -154,6 +154,127 @@ __global__ __launch_bounds__(256, (BM * BN <= 64 * 64) ? 4 : (BM * BN <= 64 * 12
     }
 }
 
+// ---- NT on 192 x 256 tiles, LDS-DMA staged (round 3; BASELINE configs[4]: M = 49 152 rows, N = H = 256) --------------------
+// At configs[4] the forward product streams 642 MB of packed rows for 164 GF: at the bf16 MFMA rate that is an HBM-bound
+// stream (107 us at 6 TB/s against 66 us of MFMA time).  The 128 x 128 kernel above moves every packed row through L2 -> LDS
+// twice (two column tiles) and the weights 768 times: 2.6 GB of L2 -> LDS traffic, delivered at ~10 TB/s = 264 us.  Here one
+// workgroup owns 192 rows x ALL 256 columns (256 workgroups = one per CU at configs[4]): every packed row is read once, 1.5 GB
+// of L2 -> LDS traffic.  512 threads = 8 waves as 2 (rows) x 4 (columns), wave tile 96 x 64 = 6 x 4 blocks of
+// v_mfma_f32_16x16x32_bf16, K-step 64.  Staging is LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write pass), 8-row x 128-B
+// pieces; the LDS image is linear per piece and XOR-swizzled through the SOURCE address (16-byte chunk c of tile row r sits at
+// chunk c ^ ((r >> 1) & 7): conflict-free ds_read_b128 for the hardware's 16-lane groups).  The HBM operand (A) runs a ring of
+// three slots = two K-steps in flight, the L2-resident weights (B) a ring of two; the DMA of step t+2 / t+1 stays in flight
+// across the barrier of step t (counted s_waitcnt vmcnt(3) + raw s_barrier: __syncthreads would drain it).
+constexpr int N8_BM = 192, N8_BN = 256, N8_A = N8_BM * 128, N8_BH = N8_BN * 64, N8_LDS = 3 * N8_A + 4 * N8_BH;
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// ... with the non-temporal hint: bytes that ONE workgroup reads ONCE (the packed rows) must not push the weights every CU
+// re-reads out of the 4 MB L2
+__device__ __forceinline__ void glds16_nt(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// Rings: A (the HBM operand) three K-step slots of 192 rows x 128 B: A(t+2) is issued when step t starts, two steps ahead;
+// B (the weights, L2-resident but 32 KB per K-step for every CU) FOUR half-step slots of 256 rows x 64 B (k32 halves): half h+3
+// is issued when half h starts (a ring of two whole K-step slots could only run one step ahead -- the slot of step t+1 is being
+// read until step t-1 ends -- and every K-step then waited ~2 us for its weights: 214 us).  A step is two phases (k32 halves), each
+// closed by a counted wait + raw barrier; DMA issue order  ... Bh(odd), A, Bh(even), Bh(odd), A ...  makes the counts 10 / 7.
+// Measured at configs[4] (M = 49 152, Kc = 6 528; tools: NCX_NT8_VAR timing ablations of round 3, since removed): 128 x 128 kernel 265 us;
+// this kernel 215-228 us, 203 with the non-temporal hint on the packed rows (they are read once by one CU and otherwise push the
+// 3.3 MB of weights out of the 4 MB L2s).  What it waits for is data delivery, not the matrix pipe: without any MFMA it takes the
+// same time; with the rows coming from L2 (every workgroup streaming the same block) 165-170 us = 1.6 us per 56 KB K-step = 35 GB/s
+// per CU; the rows addressed as if the pack were stored tile by tile (1 KiB contiguous per DMA instruction) 189 us (not adopted: the
+// pack and the TN kernel would have to follow).
+__global__ __launch_bounds__(512, 2) void gemm_bf16_nt8_kernel(const u16* __restrict__ A, int M, const u16* __restrict__ B, int Nrows,
+                                                               int N, int Kc, float* __restrict__ out, long long ldo, const EpiArgs epi) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_bf16[];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 2) * 96, wn0 = (wave & 3) * 64;
+    const int m0 = blockIdx.x * N8_BM;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_bf16;   // LDS byte address of the A ring (the B ring follows)
+    // loader roles.  A: this wave's pieces are tile rows 8 (wave + 8 i) .. + 7 (i < 3), lane -> row lane >> 3, physical chunk lane & 7 of
+    // the 128-B row, holding logical chunk pc ^ ((row >> 1) & 7).  B halves: pieces of 16 rows x 64 B, rows 16 (2 wave + i) .. + 15
+    // (i < 2), lane -> row lane >> 2, physical chunk lane & 3, holding logical chunk pc ^ g(row), g = (-(row >> 2)) & 3.
+    const u16* srcA[3]; const u16* srcB[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const int r = 8 * (wave + 8 * i) + (lane >> 3); srcA[i] = A + (long long)min(m0 + r, M - 1) * Kc + 8 * ((lane & 7) ^ ((r >> 1) & 7)); }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int r = 16 * (2 * wave + i) + (lane >> 2); srcB[i] = B + (long long)min(r, Nrows - 1) * Kc + 8 * ((lane & 3) ^ ((4 - ((r >> 2) & 3)) & 3)); }
+    const int nk = Kc / 64;
+    auto issueA = [&](int kt) __attribute__((always_inline)) {
+        const int k = min(kt, nk - 1);
+        const unsigned dst = lds0 + (unsigned)(kt % 3) * N8_A + (unsigned)wave * 1024u;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) glds16_nt(srcA[i] + (long long)k * 64, dst + (unsigned)i * 8192u);
+    };
+    auto issueBh = [&](int h) __attribute__((always_inline)) {
+        const int k = min(h, 2 * nk - 1);
+        const unsigned dst = lds0 + 3u * N8_A + (unsigned)(h & 3) * N8_BH + (unsigned)wave * 2048u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(srcB[i] + (long long)k * 32, dst + (unsigned)i * 1024u);
+    };
+    f32x4 acc[6][4];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int swa = li >> 1;                                                      // (row >> 1) & 7 of this lane's A fragment rows
+    const int chb = (lk ^ ((4 - (li >> 2)) & 3)) * 16;                            // this lane's physical chunk in a B half row
+    auto phase = [&](int kt, int s) __attribute__((always_inline)) {             // the k32 half s of K-step kt
+        const unsigned char* ta = smem_bf16 + (kt % 3) * N8_A + (wm0 + li) * 128 + ((4 * s + lk) ^ swa) * 16;
+        const unsigned char* tb = smem_bf16 + 3 * N8_A + ((2 * kt + s) & 3) * N8_BH + (wn0 + li) * 64 + chb;
+        bf16x8 af[6], bf[4];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) af[i] = *(const bf16x8*)(ta + i * 16 * 128);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = *(const bf16x8*)(tb + j * 16 * 64);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    };
+    issueBh(0); issueA(0); issueBh(1); issueA(1); issueBh(2);
+    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                              // Bh(0), A(0) landed
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < nk; ++t) {
+        issueBh(2 * t + 3);
+        issueA(t + 2);
+        phase(t, 0);
+        asm volatile("s_waitcnt vmcnt(10)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // Bh(2t+1) landed
+        __builtin_amdgcn_s_barrier();
+        issueBh(2 * t + 4);
+        phase(t, 1);
+        asm volatile("s_waitcnt vmcnt(7)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");    // Bh(2t+2), A(t+1) landed
+        __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // epilogue (row-block loop kept rolled, as in the kernel above)
+#pragma unroll 1
+    for (int i = 0; i < 6; ++i) {
+        f32x4 row[4];
+#pragma unroll
+        for (int ii = 0; ii < 6; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (ii == 0) row[j] = acc[0][j];
+                else row[j] = (ii == i) ? acc[ii][j] : row[j];
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = m0 + wm0 + 16 * i + 4 * lk + q, n = wn0 + 16 * j + li;
+                if (r < M && n < N) out[(long long)r * ldo + n] = apply_epilogue(epi, row[j][q], r, n, N);
+            }
+    }
+}
+
 // ---- TN: C[Hm, Kc] (+)= sum over rows k of A[k][m] . B[k][n], both row-major bf16 with the reduction along ROWS --------
 // The LDS image keeps the global layout ([64 k-rows][128 columns], rows padded to 288 B) and ds_read_b64_tr_b16 delivers
 // the MFMA operands transposed: lane 4q+p of a 16-lane group addresses row q, columns 4p..4p+3 of a 4 x 16 block and
@@ -317,6 +438,14 @@ int bf16_main_forward(const ncx_dims& d, const u16* xc, const u16* wc, const Epi
     // tile that puts >= 2 workgroups on every CU.  NCX_BF16_NT_CFG (0..3) overrides for experiments.
     int cfg = -1;
     { const char* e = hook_env("NCX_BF16_NT_CFG"); if (e) cfg = atoi(e); }
+    // one 192 x 256 workgroup per CU (LDS-DMA staged): all of H in one tile, >= 3/4 of the CUs busy
+    if ((cfg < 0 || cfg == 8) && d.H <= N8_BN && (d.H + 127) / 128 * 128 == N8_BN && (cfg == 8 || (long long)(M + N8_BM - 1) / N8_BM * 4 >= 3LL * num_cus())) {
+        static DevMask attr8{0};
+        NCX_HIP_TRY(set_max_lds_once(attr8, (const void*)gemm_bf16_nt8_kernel, N8_LDS));
+        hipLaunchKernelGGL(gemm_bf16_nt8_kernel, dim3((M + N8_BM - 1) / N8_BM), dim3(512), N8_LDS, s, xc, M, wc, N8_BN, d.H, cc.kc, h1, (long long)d.H, epi);
+        NCX_HIP_TRY(hipGetLastError());
+        return NCX_OK;
+    }
     if (cfg < 0) {
         const long long t128 = (long long)((M + 127) / 128) * ((d.H + 127) / 128);
         cfg = t128 >= 2LL * num_cus() ? 0 : 3;
