@@ -172,6 +172,28 @@ def test_bf16_variant_vs_bf16_oracle(B, K, H, L, dv, strict):
     assert 1e-4 < float((s16 - s32).abs().max()) <= 0.3          # eval mode: bf16 operands vs the fp32 network
 
 
+@pytest.mark.parametrize("B,K,H", [(9, 24, 256), (37, 24, 200), (13, 48, 256)])
+def test_bf16_forward_product_on_192x256_tiles_ragged(B, K, H, monkeypatch):
+    """The LDS-DMA staged 192 x 256 forward kernel of the bf16 variant (csrc/ncx_bf16.hip, gemm_bf16_nt8_kernel; the planner takes it
+    where its tiles fill the chip, i.e. at configs[4]'s size -- covered by test_configs4_shape...) forced onto small RAGGED shapes:
+    M = B K is not a multiple of 192 (clamped DMA rows, guarded stores), H below the 256-column tile, one and several workgroups.
+    Logits against the bf16 restatement, and bit-identical to the 128 x 128 kernel's (same products, same k order per element)."""
+    d = orc.Dims(K=K, dv=64, dq=50, dz=18, A=45, H=H, L=1)
+    params = orc.init_params(d, seed=5 + B, gain=3.0)
+    batch = random_case(900 + B, B, d)
+    monkeypatch.setenv("NCX_EXPERIMENT", "1")
+    monkeypatch.setenv("NCX_BF16_NT_CFG", "8")
+    s8, lr8, g8 = run_hip_bf16(d, params, batch)
+    monkeypatch.setenv("NCX_BF16_NT_CFG", "0")
+    s0, lr0, g0 = run_hip_bf16(d, params, batch)
+    s_ref, l_ref, g_ref = orc.loss_and_grads_bf16(params, d, batch)
+    assert np.abs(s8.numpy() - s_ref.numpy()).max() <= 2e-3
+    assert np.isfinite(s8.numpy()).all()
+    assert np.abs(s8.numpy() - s0.numpy()).max() <= 1e-5          # (another k-step grouping of the fp32 accumulation)
+    for k, ref in g_ref.items():
+        assert np.abs(g8[k].reshape(ref.shape) - ref.numpy()).max() <= grad_tol(k, ref.numpy(), 1e-3), k
+
+
 def test_rows_wider_than_the_register_resident_prep_path():
     """k_prep keeps rows of up to 2048 floats in registers (single pass); wider feature / answer rows take the re-reading
     path.  Both must agree with the oracle (fp32 and the bf16 variant's row pack)."""

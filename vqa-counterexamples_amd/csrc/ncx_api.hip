@@ -979,7 +979,7 @@ WsLayout ws_layout(const ncx_dims& d) {
 // configs[1]: round 1 (Gt, Sh || k_prep; dW1ak || dE) 1.236-1.253 ms/step with it vs 1.221-1.228 without; round 2 (the
 // whole answer-embedding chain || k_dw_km as well) 1.001-1.003 vs 0.985-0.992: the fork/join events cost what the
 // overlap wins and a full round of long workgroups leaves the short ones no slots, so it is OFF unless NCX_SIDE_STREAM=1.
-struct SideStream { hipStream_t s; hipEvent_t fork, join; int state; };     // state: 0 new, 1 ready, -1 unavailable
+struct SideStream { hipStream_t s; hipEvent_t fork, join; int state, mode; };     // state: 0 new, 1 ready, -1 unavailable; mode = NCX_SIDE_STREAM (1 both passes, 2 forward only, 3 backward only)
 static SideStream* side_stream() {
     static SideStream tab[16];
     int dev = 0;
@@ -988,6 +988,7 @@ static SideStream* side_stream() {
     if (t.state == 0) {
         const char* on = getenv("NCX_SIDE_STREAM");
         t.state = -1;
+        t.mode = on ? atoi(on) : 0;
         if ((on && atoi(on)) &&
             hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&t.fork, hipEventDisableTiming) == hipSuccess &&
@@ -1134,6 +1135,7 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
     // k_prep (HBM-bound) on the caller's stream  ||  Gt, Sh (small MFMA GEMMs; Sh only needs idx_ob, which k_prep
     // produces, so it gathers through img_idx directly) on the side stream
     SideStream* ss = side_stream();
+    if (ss && ss->mode == 3) ss = nullptr;
     hipStream_t s2 = ss ? ss->s : s;
     float* slab_side = ss ? (float*)(ws + w.slab2) : slab;
     const size_t slab_side_bytes = ss ? w.slab2_bytes : w.slab_bytes;
@@ -1520,7 +1522,7 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
         const bool km = dw_km_supported(d) && !bf16;
         // With the side stream the per-triplet fold kernel (a full round of long workgroups) is launched AFTER the grouped
         // launch, next to the answer-embedding chain (dW1ak, dE: short latency-bound workgroups) that waits for dGt.
-        km_deferred = want_rest && km && aemb && do1 && do2 && side_stream() != nullptr;
+        km_deferred = want_rest && km && aemb && do1 && do2 && side_stream() != nullptr && side_stream()->mode != 2;
         // the sums over its k-chunk partials ride in one launch with the split fix-up of the grouped GEMM below
         const bool km_merge = want_rest && km && !km_deferred && !hook_env("NCX_NO_MERGE_FIX");
         if (want_rest && km && !km_deferred) {      // v_other and v_mult columns in one MFMA pass (per-triplet fold)
