@@ -1,12 +1,9 @@
 set -e
 cd $GRAFT_REPO_ROOT
-bash tools/profile_round.sh r3_01 c2 > gpurun_out/pr_c2.log 2>&1
-bash tools/profile_round.sh r3_01_c3 c3 --c3 > gpurun_out/pr_c3.log 2>&1
-bash tools/profile_round.sh r3_01_c5 c5 --bf16 --K 48 --batch 1024 > gpurun_out/pr_c5.log 2>&1
-cp gpurun_out/r3_traffic.json profiles/r3_traffic.json
-python bench.py > gpurun_out/r3_01_bench.json 2> gpurun_out/r3_01_bench.err
-python bench.py --c3 --no-cpu-baseline > gpurun_out/r3_01_c3_bench.json 2>/dev/null
-python bench.py --bf16 --K 48 --batch 1024 --no-cpu-baseline > gpurun_out/r3_01_c5_bench.json 2>/dev/null
-python bench.py --steps 100 --warmup 20 --no-cpu-baseline > gpurun_out/r3_01_bench_100.json 2>/dev/null
-python bench.py --scaling strong --batch 64 --no-cpu-baseline --heldout 0 > gpurun_out/r3_01_b64.json 2>/dev/null
-tail -c 600 gpurun_out/r3_01_bench.json
+B="python bench.py --steps 30 --warmup 5 --no-cpu-baseline --heldout 0"
+for m in "0 0" "0 1" "3 1" "1 1" "2 1"; do set -- $m; env NCX_SIDE_STREAM=$1 NCX_BENCH_HIPRIO=$( [ $2 = 1 ] && echo 1 ) $B > gpurun_out/r3l.json 2>/dev/null; python - "$m" <<'PY'
+import json,sys
+d=json.loads(open('gpurun_out/r3l.json').read().strip().splitlines()[-1]); r=d['roofline']
+print(sys.argv[1], d['ms_per_step'], d['value'], {k:v['launch_ms'] for k,v in r['other'].items()})
+PY
+done
