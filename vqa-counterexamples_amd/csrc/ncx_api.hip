@@ -1096,7 +1096,7 @@ using namespace ncx;
 // =================================================================================================
 extern "C" {
 
-const char* ncx_version(void) { return "neuralcx-hip gfx950 fp32-mfma r2 (" __DATE__ ")"; }
+const char* ncx_version(void) { return "neuralcx-hip gfx950 fp32-mfma r3 (" __DATE__ ")"; }
 
 int64_t ncx_input_size(const ncx_dims* d) { return d ? (int64_t)seg_offsets(*d).din : 0; }
 
