@@ -696,3 +696,26 @@ def test_dp2_rank_without_triplets_still_steps_in_lockstep():
         assert diff.max() <= 2 * 1e-3 + 1e-6, k                    # never more than two steps of lr apart
         if k != "out.bias":
             assert (diff > 2e-6).mean() <= 0.02, (k, float((diff > 2e-6).mean()))
+
+
+def test_bench_two_ranks_on_one_card_gloo_rehearsal():
+    """`python bench.py --gpus 2` end to end on the GPU box: the launcher starts two ranks (torch.distributed.run), each builds its
+    engine on the card, the data-parallel step runs its phased backward with both gradient exchanges (5 | 2 | 4: the dGt block, then
+    the flat buffer without answer_embedding), rank 0 prints ONE JSON line with the multi-rank fields.  One card cannot host two
+    RCCL ranks, so the collective backend is gloo here (NCX_DIST_BACKEND); with RCCL the same command fails with a clear message
+    (tests/test_bench_cpu.py).  The RCCL run itself needs the driver's multi-GPU node."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["NCX_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "64",
+                        "--n_img", "4096", "--preheat-ms", "0", "--heldout", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 4 and d["warmup"] == 2
+    assert d["config"]["global_batch"] == 128 and d["config"]["per_rank_batch"] == 64 and d["config"]["parallelism"] == "dp2"
+    assert d["rccl"]["nranks"] == 2 and "gloo" in d["rccl"]["note"]
+    assert d["value"] > 0 and abs(d["value"] - 128 / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]
+    assert np.isfinite(d["config"]["final_loss"]) and 2.0 < d["config"]["final_loss"] < 4.0

@@ -329,6 +329,43 @@ def test_configs1_unconditioned_logits_vs_oracle():
     assert abs(float(lr["loss"]) - float(orc.ranking_loss(s_ref, batch["gt"]))) <= 1e-5
 
 
+def test_in_kernel_clock_stamps_of_the_forward_kernel():
+    """ncx_profile_stamps (include/neuralcx.h): while armed, every workgroup of the fp32 forward kernel leaves its entry / exit
+    stamps (shader-cycle counter and the 100 MHz constant-rate counter); the held clock comes out in the chip's range, the scores
+    are unchanged bit for bit, and a disarmed launch writes nothing."""
+    from neuralcx import ops, _lib
+    d = orc.Dims()
+    B = 512
+    rng = np.random.default_rng(3)
+    feats = (torch.randn(4096, d.dv).abs() * 0.45).to(dev())
+    idx = torch.from_numpy(rng.integers(0, 4096, size=(B, d.K + 1)).astype(np.int32)).to(dev())
+    mk = lambda *s: torch.randn(*s, device=dev())
+    b = ops.Batch(feats, idx, mk(B, d.dq) * 0.3, mk(B, d.dz), mk(B, d.K, d.dz), mk(B, d.K, d.A) * 2,
+                  torch.from_numpy(rng.integers(0, d.A, size=B).astype(np.int32)).to(dev()))
+    p = to_dev_params(orc.init_params(d, seed=42))
+    dims = ops.make_dims(b, H=d.H, L=d.L, da=d.da, A=d.A)
+    ws = ops.alloc_workspace(dims, dev())
+    s0 = ops.forward(dims, b, p, ws).clone()
+    st = torch.zeros(16 * 4096, dtype=torch.int64, device=dev())
+    _lib.profile_stamps(st)
+    try:
+        s1 = ops.forward(dims, b, p, ws).clone()
+    finally:
+        _lib.profile_stamps(None)
+    torch.cuda.synchronize()
+    assert torch.equal(s0, s1)
+    w = st.view(-1, 16).cpu()
+    w = w[w[:, 15] > w[:, 14]]
+    assert w.shape[0] == 512                                             # one record per workgroup of the 96 x 64 plan
+    mhz = (w[:, 8] - w[:, 0]).double() / (w[:, 15] - w[:, 14]).double() * 100.0
+    assert 800.0 < float(mhz.median()) < 2600.0, float(mhz.median())
+    assert set(w[:, 13].tolist()) <= set(range(8))                       # XCC ids
+    st.zero_()
+    ops.forward(dims, b, p, ws)
+    torch.cuda.synchronize()
+    assert int(st.abs().sum()) == 0                                      # disarmed: nothing written
+
+
 def test_ragged_full_width_batch_vs_oracle():
     """B = 389 at configs[1]'s widths: 9 336 candidate rows = 97 whole 96-row tiles + one with a single triplet (the four-triplet
     forward fold's ragged last tile), an odd number of triplets for the weight-gradient chunks, a batch the wave-per-triplet tail
