@@ -183,8 +183,11 @@ def test_bf16_forward_product_on_192x256_tiles_ragged(B, K, H, monkeypatch):
     batch = random_case(900 + B, B, d)
     monkeypatch.setenv("NCX_EXPERIMENT", "1")
     monkeypatch.setenv("NCX_BF16_NT_CFG", "8")
+    monkeypatch.setenv("NCX_BF16_TN8", "1")                        # ... and the 256 x 128 weight-gradient kernel (gemm_bf16_tn8_kernel)
     s8, lr8, g8 = run_hip_bf16(d, params, batch)
     monkeypatch.setenv("NCX_BF16_NT_CFG", "0")
+    monkeypatch.delenv("NCX_BF16_TN8")
+    monkeypatch.setenv("NCX_BF16_NO_TN8", "1")
     s0, lr0, g0 = run_hip_bf16(d, params, batch)
     s_ref, l_ref, g_ref = orc.loss_and_grads_bf16(params, d, batch)
     assert np.abs(s8.numpy() - s_ref.numpy()).max() <= 2e-3
@@ -192,6 +195,7 @@ def test_bf16_forward_product_on_192x256_tiles_ragged(B, K, H, monkeypatch):
     assert np.abs(s8.numpy() - s0.numpy()).max() <= 1e-5          # (another k-step grouping of the fp32 accumulation)
     for k, ref in g_ref.items():
         assert np.abs(g8[k].reshape(ref.shape) - ref.numpy()).max() <= grad_tol(k, ref.numpy(), 1e-3), k
+        assert np.abs(g8[k] - g0[k]).max() <= grad_tol(k, ref.numpy(), 1e-5), k           # (the two TN kernels: other k-chunk boundaries only)
 
 
 def test_rows_wider_than_the_register_resident_prep_path():

@@ -393,6 +393,118 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_tn_kernel(const u16* __restr
         }
 }
 
+// ---- TN on 256 x 128 tiles (round 3; BASELINE configs[4]) -----------------------------------------------------------------------
+// The 128 x 128 kernel above reads every packed row TWICE (two row tiles for H = 256) and runs 816 workgroups in 1.6 rounds of the
+// two-per-CU slots.  Here one workgroup owns ALL 256 rows of the output x 128 columns: the packed rows are read once, 51 column
+// tiles x 5 k-chunks = 255 workgroups = one round at one per CU, 5 slabs to reduce instead of 8.  512 threads = 8 waves as 4 (rows)
+// x 2 (columns), the same 64 x 64 wave tile and transposed LDS reads as above; the dpre tile's 512-byte rows are padded to 544 B
+// (= 32 mod 256, the same bank pattern as the 288-byte rows).
+constexpr int TN8_PA = 544, TN8_PB = 288, TN8_LDS = 2 * 64 * (TN8_PA + TN8_PB);
+__global__ __launch_bounds__(512, 2) void gemm_bf16_tn8_kernel(const u16* __restrict__ A, int lda, const u16* __restrict__ B, int ldb,
+                                                               int rows, int chunk_rows, int S, float* __restrict__ slab, int H, int Kc) {
+    constexpr int A_BYTES = 64 * TN8_PA, B_BYTES = 64 * TN8_PB;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem_bf16[];
+    unsigned char* const lds_a = smem_bf16;
+    unsigned char* const lds_b = smem_bf16 + 2 * A_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int z = blockIdx.x % S, tn = blockIdx.x / S;
+    const int n0 = tn * 128;
+    const int k0 = z * chunk_rows, k1 = min(k0 + chunk_rows, rows);
+    if (k0 >= rows) return;                                      // empty chunk (uniform per workgroup)
+    // loader: A tile 64 rows x 32 chunks of 16 B (4 per thread: rows ar + 16 i), B tile 64 rows x 16 chunks (2 per thread: rows br + 32 i)
+    const int ar = tid >> 5, ac = tid & 31, br = tid >> 4, bc = tid & 15;
+    const u16* pa = A + 8 * ac;
+    const u16* pb = B + n0 + 8 * bc;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 ra0[4], rb0[2], ra1[4], rb1[2];
+    unsigned ka0[4], kb0[2], ka1[4], kb1[2];
+    auto issue_m = [&](u32x4 (&ra)[4], u32x4 (&rb)[2], unsigned (&ka)[4], unsigned (&kb)[2], int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + kt * 64 + ar + 16 * i;
+            ra[i] = *(const u32x4*)(pa + (long long)min(k, rows - 1) * lda);
+            ka[i] = k < k1 ? 0xFFFFFFFFu : 0u;                   // (AND mask at store time: no branch around the load)
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = k0 + kt * 64 + br + 32 * i;
+            rb[i] = __builtin_nontemporal_load((const u32x4*)(pb + (long long)min(k, rows - 1) * ldb));     // (the packed rows: read once)
+            kb[i] = k < k1 ? 0xFFFFFFFFu : 0u;
+        }
+    };
+    auto stash_m = [&](const u32x4 (&ra)[4], const u32x4 (&rb)[2], const unsigned (&ka)[4], const unsigned (&kb)[2], int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(u32x4*)(lds_a + buf * A_BYTES + (ar + 16 * i) * TN8_PA + ac * 16) = ra[i] & ka[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *(u32x4*)(lds_b + buf * B_BYTES + (br + 32 * i) * TN8_PB + bc * 16) = rb[i] & kb[i];
+    };
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+    const int tq = li >> 2, tp = li & 3;                          // transposed-read role of this lane inside its 16-lane group
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const unsigned char* ta = lds_a + buf * A_BYTES + (4 * lk + tq) * TN8_PA + (wm0 + 4 * tp) * 2;
+        const unsigned char* tb = lds_b + buf * B_BYTES + (4 * lk + tq) * TN8_PB + (wn0 + 4 * tp) * 2;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned char* p = ta + s * 32 * TN8_PA + i * 32;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 16 * TN8_PA));
+                af[i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned char* p = tb + s * 32 * TN8_PB + j * 32;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 16 * TN8_PB));
+                bf[j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    const int nk = ((k1 - k0 + 63) / 64 + 1) & ~1;               // even; rows at or beyond k1 load as zeros (see the kernel above)
+    issue_m(ra0, rb0, ka0, kb0, 0);
+    issue_m(ra1, rb1, ka1, kb1, 1);
+    stash_m(ra0, rb0, ka0, kb0, 0);
+    __syncthreads();
+    for (int t2 = 0; t2 < nk; t2 += 2) {
+        issue_m(ra0, rb0, ka0, kb0, t2 + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(0);
+        __builtin_amdgcn_sched_barrier(0);
+        stash_m(ra1, rb1, ka1, kb1, 1);
+        __syncthreads();
+        issue_m(ra1, rb1, ka1, kb1, t2 + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(1);
+        __builtin_amdgcn_sched_barrier(0);
+        stash_m(ra0, rb0, ka0, kb0, 0);
+        __syncthreads();
+    }
+    float* dst = slab + (long long)z * H * Kc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = wm0 + 16 * i + 4 * lk + q;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn0 + 16 * j + li;
+                if (m < H && n < Kc) dst[(long long)m * Kc + n] = acc[i][j][q];
+            }
+        }
+}
+
 // dWc[h][c] = sum of the non-empty k-chunk slabs in fixed order, scattered to d linear_1.weight / dGt
 __global__ __launch_bounds__(256) void k_bf16_reduce_dwc(ncx_dims d, Bf16Cols cc, SegOffsets o, const float* __restrict__ slab, int nz,
                                                          float* __restrict__ g_w1, float* __restrict__ dgt) {
@@ -470,16 +582,30 @@ int bf16_dw1c(const ncx_dims& d, const float* dpre, u16* dpre_bf, const u16* xc,
             hipLaunchKernelGGL(k_dpre_to_bf16<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dpre, M, d.H, Hp, dpre_bf);
         NCX_HIP_TRY(hipGetLastError());
     }
+    int nz;
+    // all 256 output rows in one workgroup (the packed rows read once), S k-chunks so that tiles x S fills one round of the CUs
+    const int tiles_n8 = cc.kc / 128;
+    int S8 = num_cus() / tiles_n8; if (S8 > BF16_SPLIT) S8 = BF16_SPLIT;
+    const bool tn8 = Hp == 256 && S8 >= 2 && ((long long)M >= 64LL * 16 * S8 || hook_env("NCX_BF16_TN8")) && !hook_env("NCX_BF16_NO_TN8");
+    if (tn8) {
+        static DevMask attr8{0};
+        NCX_HIP_TRY(set_max_lds_once(attr8, (const void*)gemm_bf16_tn8_kernel, TN8_LDS));
+        const int chunk = (int)(((long long)(M + S8 - 1) / S8 + 63) / 64 * 64);
+        nz = (M + chunk - 1) / chunk;
+        hipLaunchKernelGGL(gemm_bf16_tn8_kernel, dim3(tiles_n8 * S8), dim3(512), TN8_LDS, s, (const u16*)dpre_bf, Hp, xc, cc.kc, M, chunk, S8, slab, d.H, cc.kc);
+        NCX_HIP_TRY(hipGetLastError());
+    } else {
     constexpr int BM = 128, BN = 128;
     const int lds = 4 * 64 * TN_PITCH;
     static DevMask attr{0};
     NCX_HIP_TRY(set_max_lds_once(attr, (const void*)gemm_bf16_tn_kernel<BM, BN>, lds));
     const int chunk = (int)(((long long)(M + BF16_SPLIT - 1) / BF16_SPLIT + 63) / 64 * 64);
-    const int nz = (M + chunk - 1) / chunk;
+    nz = (M + chunk - 1) / chunk;
     const int tiles_m = Hp / BM, tiles_n = cc.kc / BN;
     hipLaunchKernelGGL((gemm_bf16_tn_kernel<BM, BN>), dim3(tiles_m * tiles_n * BF16_SPLIT), dim3(256), lds, s, (const u16*)dpre_bf, Hp,
                        xc, cc.kc, M, chunk, tiles_m, BF16_SPLIT, slab, d.H, cc.kc);
     NCX_HIP_TRY(hipGetLastError());
+    }
     const long long n = (long long)d.H * cc.raw;
     hipLaunchKernelGGL(k_bf16_reduce_dwc, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, cc, seg_offsets(d), (const float*)slab, nz,
                        g_w1, dgt);
