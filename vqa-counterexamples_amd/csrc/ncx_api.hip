@@ -1738,6 +1738,14 @@ int ncx_vqa_forward(const ncx_dims* dp, const float* feats, const int32_t* img_i
         a.out[0] = hq; a.ldo[0] = RZ; a.n_cols[0] = RZ;
         rc = run_gemm_impl(a, FORM_NT, plans[1], slab, w.slab_bytes, m.bhq, s); if (rc) return rc;
     }
+    if (d.dv % 32 == 0 && d.dv >= 64 && m.dhv >= 4 && !hook_env("NCX_VQA_NO_MAIN")) {
+        // x_v on the fused forward kernel (ncx_main.h): one gathered segment, bias + activation in the epilogue (round 3: 249 -> see DESIGN 5b)
+        MainArgs a{}; a.M = Mv; a.N = m.dhv; a.nseg = 1;
+        a.seg[0].kind = MK_GATHER; a.seg[0].a = feats; a.seg[0].lda = d.dv; a.seg[0].idx = img_idx; a.seg[0].klen = d.dv;
+        a.seg[0].b = m.wv; a.seg[0].ldb = d.dv;
+        a.out = xv; a.ldo = m.dhv; a.epi.bias = m.bv; a.epi.relu = m.act_v; a.split = 1;
+        rc = main_forward(a, s); if (rc) return rc;
+    } else
     {   // x_v = act_v(gather(feats, img_idx) . Wv^T + bv) for the B*(K+1) images      fusion.py:82-87 (+ the host gather)
         GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = Mv;
         a.a[0] = x_gather(feats, d.dv, img_idx, Mv, d.dv); a.b[0] = x_plain(m.wv, d.dv, m.dhv, d.dv); a.klen[0] = d.dv;

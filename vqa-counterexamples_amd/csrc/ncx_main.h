@@ -783,6 +783,7 @@ static inline int launch_main_fwd(MainArgs& a, hipStream_t s) {
     }
     if (is({G, X, P, P, S})) return launch_main_fwd_seq<CFG, false, G, X, P, P, S>(a, s);
     if (is({P}))             return launch_main_fwd_seq<CFG, false, P>(a, s);
+    if (is({G}))             return launch_main_fwd_seq<CFG, false, G>(a, s);          // (the MUTAN producer's x_v: one gathered segment)
     if (is({G, P, P, S}))    return launch_main_fwd_seq<CFG, false, G, P, P, S>(a, s);
     if (is({G, X, P, P, P})) return launch_main_fwd_seq<CFG, false, G, X, P, P, P>(a, s);
     if (is({G, P, P, P}))    return launch_main_fwd_seq<CFG, false, G, P, P, P>(a, s);
