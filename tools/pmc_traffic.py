@@ -48,7 +48,7 @@ out = {}
 bf16 = any("gemm_bf16_nt" in k for k in fetch) and key == "c5"
 if bf16:
     out["MAIN"] = total([part(("gemm_bf16_nt8",)) or part(("gemm_bf16_nt_kernel<128",))])
-    out["DW1C"] = total([part(("k_dpre_to_bf16",)), part(("gemm_bf16_tn_kernel",)), part(("k_bf16_reduce_dwc",))])
+    out["DW1C"] = total([part(("k_dpre_to_bf16",)), part(("gemm_bf16_tn8_kernel",)) or part(("gemm_bf16_tn_kernel",)), part(("k_bf16_reduce_dwc",))])
 else:
     out["MAIN"] = total([part(("k_main_fwd", "MainCfg<96, 64")) or part(("k_main_fwd",))])
     out["DW1C"] = total([part(("k_dw_km<",)), part(("seg_gemm_kernel<128, 64, false, false",)), part(("k_dw_km_reduce_fixup",))])
