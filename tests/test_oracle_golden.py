@@ -89,3 +89,28 @@ def test_mutan_vqa_forward_restatement(name):
     a_o, z_o, a_k, z_k = orc.mutan_vqa_forward(vp, batch["image_features"], batch["q_emb"], int(g["vqa_R"]))
     for got, key in ((a_o, "a_orig"), (z_o, "z_orig"), (a_k, "a_knns"), (z_k, "z_knns")):
         assert np.abs(got.numpy() - g[key]).max() <= 2e-6 * max(1.0, np.abs(g[key]).max()), key
+
+
+def test_faithful_cpu_model_with_shared_dropout_masks_equals_the_functional_oracle():
+    """bench.py's CPU baseline trains oracle.FaithfulCPUModel with the counter-based dropout masks the HIP kernels use
+    (keep_masks) so that both sides see identical training; with the same masks the module must reproduce the functional
+    restatement (forward_faithful) exactly, and without masks it falls back to torch's own Dropout."""
+    d = orc.Dims(dv=32, dq=24, dz=8, A=20, H=16, L=2)
+    B = 5
+    rng = np.random.default_rng(0)
+    t = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+    x = dict(image_features=t(np.abs(rng.standard_normal((B, d.K + 1, d.dv)))), q_emb=t(rng.standard_normal((B, d.dq))),
+             z_orig=t(rng.standard_normal((B, d.dz))), z_knns=t(rng.standard_normal((B, d.K, d.dz))),
+             a_knns=t(rng.standard_normal((B, d.K, d.A))), answer_aids=torch.from_numpy(rng.integers(0, d.A, size=B)))
+    m = orc.FaithfulCPUModel(d, drop_p=0.25, seed=3)
+    params = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    masks = [orc.dropout_keep_mask(0x1234567, l, B * d.K, d.H, 0.25) for l in (1, 2)]
+    m.train(); m.keep_masks = masks
+    s_mod = m(x["image_features"], x["q_emb"], x["z_orig"], x["z_knns"], x["a_knns"], x["answer_aids"])
+    s_fun = orc.forward_faithful(params, d, x["image_features"], x["q_emb"], x["z_orig"], x["z_knns"], x["a_knns"], x["answer_aids"],
+                                 drop_p=0.25, keep_masks=masks)
+    assert torch.equal(s_mod.detach(), s_fun)
+    m.eval()                                                     # evaluation ignores the masks (dropout is the identity)
+    s_eval = m(x["image_features"], x["q_emb"], x["z_orig"], x["z_knns"], x["a_knns"], x["answer_aids"])
+    s_ref = orc.forward_faithful(params, d, x["image_features"], x["q_emb"], x["z_orig"], x["z_knns"], x["a_knns"], x["answer_aids"])
+    assert torch.equal(s_eval.detach(), s_ref)
