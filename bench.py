@@ -276,11 +276,13 @@ def main():
     for i in range(args.warmup):
         r = step(i)
     fence()
+    eng.comm_profile = world > 1                    # (events around the two waits for the gradient exchange: the exposed part of it)
     t0 = time.perf_counter()
     for i in range(args.steps):
         r = step(args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
+    eng.comm_profile = False
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -427,6 +429,11 @@ def main():
             out["recall_note"] = ("HIP path, %d held-out planted synthetic triplets, after %d training steps (chance: 0.0417 / 0.2083)"
                                   % (args.heldout, args.warmup + args.steps))
         if world > 1:
+            stall = None
+            if eng.comm_events:                      # rank 0's compute stream: time spent waiting for bucket 1 / bucket 2 per step
+                w1 = [e[0].elapsed_time(e[1]) for e in eng.comm_events]; w2 = [e[2].elapsed_time(e[3]) for e in eng.comm_events]
+                stall = dict(bucket1_ms=round(sum(w1) / len(w1), 4), bucket2_ms=round(sum(w2) / len(w2), 4),
+                             note="mean time per step rank 0's compute stream waits for each gradient bucket (what the backward did not hide)")
             if backend == "nccl":
                 v = torch.cuda.nccl.version()
                 out["rccl"] = dict(nranks=world, version=".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v),
@@ -434,6 +441,8 @@ def main():
                                               % (2 * c["H"] * ((c["A"] + 3) // 4 * 4) * 4 / 1e6, (eng.params.numel - eng.params.offsets["linear_1.weight"]) * 4 / 1e6))
             else:
                 out["rccl"] = dict(nranks=world, version=None, note="NCX_DIST_BACKEND=%s rehearsal: NOT RCCL" % backend)
+            if stall:
+                out["rccl"]["exposed_wait"] = stall
         if not args.no_cpu_baseline and world == 1 and (c["dv"], c["K"]) == (2048, 24):
             out["cpu_baseline"] = cpu_baseline(dev, data.feats, steps=args.cpu_steps, heldout=args.heldout)
         print(json.dumps(out), flush=True)

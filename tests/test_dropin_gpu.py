@@ -717,5 +717,6 @@ def test_bench_two_ranks_on_one_card_gloo_rehearsal():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 4 and d["warmup"] == 2
     assert d["config"]["global_batch"] == 128 and d["config"]["per_rank_batch"] == 64 and d["config"]["parallelism"] == "dp2"
     assert d["rccl"]["nranks"] == 2 and "gloo" in d["rccl"]["note"]
+    assert d["rccl"]["exposed_wait"]["bucket1_ms"] >= 0 and d["rccl"]["exposed_wait"]["bucket2_ms"] >= 0      # (stall of the compute stream per bucket)
     assert d["value"] > 0 and abs(d["value"] - 128 / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]
     assert np.isfinite(d["config"]["final_loss"]) and 2.0 < d["config"]["final_loss"] < 4.0

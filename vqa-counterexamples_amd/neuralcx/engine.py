@@ -79,6 +79,11 @@ class NeuralCXEngine:
         self.rank = 0
         self._weights_version = 0
         self._gt_key = None
+        # data parallelism: when set (bench.py), every step records events around the two waits for the gradient exchange on the
+        # compute stream: comm_events = [(before wait 1, after wait 1, before wait 2, after wait 2), ...] -- how long the step
+        # stalls for each bucket, i.e. the part of the all-reduce the backward did NOT hide
+        self.comm_profile = False
+        self.comm_events = []
 
     # ---- parameters --------------------------------------------------------------------------------------
     def init_parameters(self, seed=42, emb=None):
@@ -178,12 +183,17 @@ class NeuralCXEngine:
                 h1 = torch.distributed.all_reduce(ops.ws_dgt_view(d, self._ws), group=self.pg, async_op=True)
                 ops.backward(d, batch, f, self._ws, r["dscores"], self.grads.fields(), phase=2)
                 h2 = torch.distributed.all_reduce(self.grads.flat[n_emb:], group=self.pg, async_op=True)
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if self.comm_profile else None
+                if ev: ev[0].record()
                 h1.wait()
+                if ev: ev[1].record()
                 ops.backward(d, batch, f, self._ws, r["dscores"], self.grads.fields(), phase=4)
                 # answer_embedding's gradient is complete on every rank: its Adam slice also runs under bucket 2
                 ops.adam_step(self.params.flat[:n_emb], self.grads.flat[:n_emb], self.exp_avg[:n_emb], self.exp_avg_sq[:n_emb],
                               self.step_count, lr=self.lr)
+                if ev: ev[2].record()
                 h2.wait()
+                if ev: ev[3].record(); self.comm_events.append(ev)
                 ops.adam_step(self.params.flat[n_emb:], self.grads.flat[n_emb:], self.exp_avg[n_emb:], self.exp_avg_sq[n_emb:],
                               self.step_count, lr=self.lr)
                 r["scores"] = scores
