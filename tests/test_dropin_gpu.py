@@ -162,7 +162,7 @@ def test_full_width_training_against_the_fp64_referee_and_heldout_recall():
       * steps 0 .. 39, against the referee: |loss_HIP - loss_f64| <= 2e-4 (round 1's bound; step 0: <= 1e-5);
       * after 40 steps, 4 096 held-out triplets HIP vs referee: Recall@1 / @5 totals within 0.1 pt, and every triplet
         whose ground truth is further than 1e-3 from its rank boundary classified identically (count of excluded
-        near-ties reported, <= 1 %);
+        near-ties reported: 17 / 36 of 4 096 measured, bound 2 %);
       * after 200 steps (Recall@5 > 0.40, chance 0.208) the three trajectories are decorrelated: the fp32 reference and the
         HIP run each classify ~60 of the 4 096 triplets differently from the referee at k = 5 (measured: 61 and 61; 25 and 18
         at k = 1), i.e. the REFERENCE's Recall@5 is only defined to ~+-0.2 pt at this horizon (0.07 .. 0.22 pt observed on two
@@ -230,7 +230,7 @@ def test_full_width_training_against_the_fp64_referee_and_heldout_recall():
                 margin = np.minimum(np.abs(sg - srt[:, k - 1]) + (R["f64"] < k) * 1e9, np.abs(sg - srt[:, k]) + (R["f64"] >= k) * 1e9)
                 near = margin < 1e-3                                   # gt within 1e-3 of the side of the boundary it would cross
                 assert ((R["hip"] < k) == (R["f64"] < k))[~near].all(), k
-                assert near.mean() <= 0.01, (k, int(near.sum()))
+                assert near.mean() <= 0.02, (k, int(near.sum()))           # (measured: 17 and 36 of 4 096)
                 n_hip, n_ref = int((R["hip"] < k).sum()), int((R["f64"] < k).sum())
                 assert abs(n_hip - n_ref) <= 0.001 * HELD, (k, n_hip, n_ref)
                 print("after 40 steps: Recall@%d HIP %d / f64 %d of %d (near-ties excluded from the per-triplet check: %d)" % (k, n_hip, n_ref, HELD, int(near.sum())))
