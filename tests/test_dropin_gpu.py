@@ -596,10 +596,17 @@ def test_module_is_reentrant_two_forwards_before_backward():
     with pytest.raises(IndexError):
         m.check_answer_ids()
     m(ia[0], ia[1], torch.full_like(ia[2], -1))
-    torch.cuda.synchronize()
-    with pytest.raises(IndexError):                                # ... or surfaces at the next forward
-        m(ia[0], ia[1], ia[2])
-    m(ia[0], ia[1], ia[2]); m.check_answer_ids()                   # and the flag clears
+    # ... or surfaces at a later forward: at the very next one if the flag's copy has landed by then, else -- the host runs ahead of
+    # the GPU -- at the one after; VALID forwards in between do not hide the verdict (the device flag is sticky until reported)
+    raised = 0
+    for i in range(3):
+        try:
+            m(ia[0], ia[1], ia[2])
+        except IndexError:
+            raised += 1
+        torch.cuda.synchronize()
+    assert raised == 1
+    m(ia[0], ia[1], ia[2]); m.check_answer_ids()                   # and the flag clears once reported
 
 
 def test_cli_resume_continues_bit_for_bit(tmp_path, capsys):

@@ -179,7 +179,7 @@ class NeuralModel(CXModelBase):
         call = dict(dims=d, batch=batch, names=names, pool=self._pool, record=record)      # per-call snapshot (re-entrant: see ops.WorkspacePool)
         return ops.NeuralCXFunction.apply(call, *tensors)
 
-    _aid_host, _aid_event, _aid_pending = None, None, False
+    _aid_host, _aid_event, _aid_pending, _aid_flag = None, None, False, None
 
     def check_answer_ids(self, wait=True):
         """Raises IndexError if the previous forward saw an answer id outside [0, ans_size) (what nn.Embedding raises at
@@ -192,7 +192,8 @@ class NeuralModel(CXModelBase):
             self._aid_event.synchronize()
         self._aid_pending = False
         if bool(self._aid_host[0]):
-            raise IndexError("answer_aids outside [0, %d) in the previous forward" % self.ans_size)
+            self._aid_flag.zero_()                                  # (sticky on the device until reported)
+            raise IndexError("answer_aids outside [0, %d) in a previous forward" % self.ans_size)
 
     def forward(self, image_features, question_wids, answer_aids):
         spec = self.model_spec
@@ -220,13 +221,17 @@ class NeuralModel(CXModelBase):
             # nn.Embedding raises on a bad index (cx.py:280); the kernels gather / scatter embedding rows by it.  No host
             # sync per forward: the ids are clamped for the kernels, the verdict goes to a device flag whose copy to pinned
             # host memory is read at the NEXT forward (long complete by then) or by check_answer_ids() -- the error of
-            # step n surfaces at step n + 1 at the latest, before its scores can have been used for a second update.
+            # step n surfaces as soon as its copy has landed (checked at every later forward) or when the caller asks.  The flag is
+            # STICKY on the device (or-ed across forwards, cleared only when reported): the host runs ahead of the GPU, so the
+            # copy of step n has usually not landed when step n + 1 is enqueued, and a later copy must still carry step n's verdict.
             self.check_answer_ids(wait=False)
-            bad = ((answer_aids < 0) | (answer_aids >= self.ans_size)).any()
+            bad = ((answer_aids < 0) | (answer_aids >= self.ans_size)).any().view(1)
             answer_aids = answer_aids.clamp(0, self.ans_size - 1)
-            if self._aid_host is None:
+            if self._aid_host is None or self._aid_flag is None or self._aid_flag.device != dev:
                 self._aid_host = torch.zeros(1, dtype=torch.bool).pin_memory() if dev.type == "cuda" else torch.zeros(1, dtype=torch.bool)
-            self._aid_host.copy_(bad.view(1), non_blocking=True)
+                self._aid_flag = torch.zeros(1, dtype=torch.bool, device=dev)
+            self._aid_flag |= bad
+            self._aid_host.copy_(self._aid_flag, non_blocking=True)
             if dev.type == "cuda":
                 self._aid_event = torch.cuda.Event()
                 self._aid_event.record(torch.cuda.current_stream(dev))
