@@ -368,7 +368,7 @@ def main():
         # (K = 24) or 64 (K = 48) row blocks per triplet for the two 2048-deep segments at once: 4 MFMA row blocks instead of 2 x 3)
         pad32 = lambda n: (n + 31) // 32 * 32
         rest_cols = pad32(c["K"] + 1) + pad32(c["dz"]) + pad32(c["A"])
-        fold_fwd = plans["MAIN"]["tile"].startswith(("48x64", "96x64"))
+        fold_fwd = plans["MAIN"]["tile"].startswith(("48x64", "96x64", "192x64"))
         blk = 32 if c["K"] == 24 else 64
         executed = {"MAIN": 2.0 * c["H"] * ((args.batch * blk if fold_fwd else 2 * M) * c["dv"] + M * rest_cols),
                     "DW1C": (2.0 * c["H"] * M * (c["dv"] + c["K"] + 1 + c["dz"] + c["A"]) + 2.0 * args.batch * c["H"] * s_cols) if c["K"] % 24 == 0 and args.batch >= 256

@@ -276,8 +276,8 @@ int ncx_profile_end(float* ms, int32_t* ids, int32_t cap);
  * launch, else the launch is not stamped).  ncx_profile_stamps(NULL, 0) disarms.  The timed product path never arms it
  * (bench.py stamps a separate diagnostic pass after its timed region). */
 int ncx_profile_stamps(unsigned long long* stamps, int64_t words);
-/* out6 = {form (0 NT,1 TN,2 NN), M, N, 32-deep k-steps, tile cfg (0 64x64, 1 128x128, 2 96x128),
- *         aligned k-chunks per output tile (1 = no split)} */
+/* out6 = {form (0 NT,1 TN,2 NN), M, N, 32-deep k-steps, tile cfg (0 64x64, 1 128x128, 2 96x128, 3 96x64, 4 128x64; the fused forward
+ *         kernel: 5 48x128, 6 / 7 / 8 the per-triplet fold on 48x64 / 96x64 / 192x64 tiles), aligned k-chunks per output tile (1 = no split)} */
 int ncx_plan_query(const ncx_dims* d, int32_t gemm_id, int32_t* out6);
 /* Host-only self-check of the workgroup-id <-> (tile, k-chunk) maps (XCD-aware interleaved layout, chunk-per-XCD
  * layout with its padding ids): 0 when decode/encode are mutually inverse and cover every (tile, chunk) exactly once. */

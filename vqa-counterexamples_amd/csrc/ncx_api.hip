@@ -1163,7 +1163,7 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
     long long main_T = ks(d.dv) * ((d.flags & NCX_F_V_MULT) ? 2 : 1) + ks(w.ldm) + ks(d.dz) + (aemb ? ks(d.A) : ks(d.da));
     // K = 24, whole 32-column tiles, no k-split: the two v segments as one pass with the per-triplet fold (ncx_main.h, MK_VFOLD)
     // (K = 48: on 96-row tiles only -- two triplets per tile -- so only where those fill the chip)
-    const bool vfold = main_fwd_dims_ok(d) && (d.flags & NCX_F_V_MULT) && (d.K == 24 || (d.K == 48 && (main_fold_rows(M, H) == 96 || hook_env("NCX_FOLD4")))) && d.dv % 32 == 0 && d.dv >= 64 &&
+    const bool vfold = main_fwd_dims_ok(d) && (d.flags & NCX_F_V_MULT) && (d.K == 24 || (d.K == 48 && (main_fold_rows(M, H) >= 96 || hook_env("NCX_FOLD4") || hook_env("NCX_FOLD8")))) && d.dv % 32 == 0 && d.dv >= 64 &&
                        main_split(M, H, main_T) == 1 && !hook_env("NCX_NO_VFOLD");
     // Measured at configs[1]: inside the plain chain the distance costs the kernel 12 us and saves k_prep 30; inside the fold's
     // 48 x 64 tiles (a quarter of the MFMA work per vector instruction) it costs 31 us: there k_prep keeps computing it.
@@ -1253,7 +1253,7 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
             a.split = main_split(M, H, T); a.slab = (float*)(ws + w.mslab);
             if (a.split > 1 && (size_t)a.split * M * H * 4 > w.mslab_bytes) return NCX_E_WORKSPACE;
         }
-        if (g_stamps && a.split <= 1 && (long long)(((M + 47) / 48 + 7) / 8 * 8) * ((H + 63) / 64) * 16 <= g_stamp_words) a.stamps = g_stamps;   // (bound: the smallest tile)
+        if (g_stamps && a.split <= 1 && (long long)(((M + 47) / 48 + 7) / 8 * 8) * ((H + 63) / 64) * 16 <= g_stamp_words) a.stamps = g_stamps;   // (bound: the smallest tile = the most workgroups)
         rc = prof_open(U_MAIN, s); if (rc) return rc;
         rc = main_forward(a, s); if (rc) return rc;
         rc = prof_close(U_MAIN, s); if (rc) return rc;
@@ -1847,9 +1847,9 @@ int ncx_plan_query(const ncx_dims* d, int32_t gemm_id, int32_t* out6) {
     if (fast) {
         const long long M = (long long)d->B * d->K, T = u[gemm_id].ksteps;
         const int sp = main_split(M, d->H, T);
-        const bool vfold = gemm_id == U_MAIN && (d->flags & NCX_F_V_MULT) && (d->K == 24 || (d->K == 48 && main_fold_rows(M, d->H) == 96)) && d->dv % 32 == 0 && d->dv >= 64 && sp == 1;
+        const bool vfold = gemm_id == U_MAIN && (d->flags & NCX_F_V_MULT) && (d->K == 24 || (d->K == 48 && main_fold_rows(M, d->H) >= 96)) && d->dv % 32 == 0 && d->dv >= 64 && sp == 1;
         const long long tiles96 = ((M + 95) / 96) * ((d->H + 127) / 128);
-        out6[4] = vfold ? ((main_fold_rows(M, d->H) == 96 || d->K == 48) ? 7 : 6) : (sp == 1 && tiles96 * 10 >= (long long)num_cus() * 9) ? CFG_96x128 : 5;
+        out6[4] = vfold ? (main_fold_rows(M, d->H) == 192 ? 8 : (main_fold_rows(M, d->H) == 96 || d->K == 48) ? 7 : 6) : (sp == 1 && tiles96 * 10 >= (long long)num_cus() * 9) ? CFG_96x128 : 5;
         out6[5] = sp;
     }
     return NCX_OK;

@@ -39,14 +39,16 @@ constexpr int MF_BK = 32, MF_P = MF_BK + 4, MF_T = 256;
 enum { LK_PLAIN = 0, LK_MUL = 1, LK_SOFTMAX = 2 };
 template <int V> struct IntC { static constexpr int value = V; };
 
-// BM x BN tile, 4 waves as WGM x WGN, DEPTH register sets of global loads in flight, OCC workgroups per CU (register budget)
-template <int BM_, int BN_, int WGM_, int WGN_, int DEPTH_, int OCC_>
+// BM x BN tile, T threads = T / 64 waves as WGM x WGN, DEPTH register sets of global loads in flight, OCC = waves per SIMD the register
+// budget is sized for (workgroups per CU x T / 256)
+template <int BM_, int BN_, int WGM_, int WGN_, int DEPTH_, int OCC_, int T_ = MF_T>
 struct MainCfg {
-    static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, DEPTH = DEPTH_, OCC = OCC_;
-    static constexpr int BM_LDS = (BM + 31) / 32 * 32;            // A rows held in LDS (a multiple of the 32-row loader pass)
+    static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, DEPTH = DEPTH_, OCC = OCC_, T = T_;
+    static constexpr int RP = T / 8;                                // tile rows per loader pass (8 threads x 16 bytes per 32-float row)
+    static constexpr int BM_LDS = (BM + RP - 1) / RP * RP;        // A rows held in LDS (a multiple of the loader pass)
     static constexpr int LDS = 2 * (BM_LDS + BN) * MF_P * 4;
-    static constexpr int LDS_FOLD = BM == 96 ? 2 * (128 + 128) * MF_P * 4      // MK_VFOLD on 96-row tiles: A 4 x 32 rows, W_k | W_m 2 x 64 rows
-                                             : 2 * (80 + 2 * 64) * MF_P * 4;    // MK_VFOLD on 48-row tiles: A 80 rows, two effective weight tiles
+    static constexpr int LDS_FOLD = BM % 96 == 0 ? 2 * (32 * (T / 64) + 128) * MF_P * 4   // MK_VFOLD, one triplet per wave: A 32 rows per wave, W_k | W_m 2 x 64 rows
+                                                 : 2 * (80 + 2 * 64) * MF_P * 4;          // MK_VFOLD on 48-row tiles: A 80 rows, two effective weight tiles
 };
 
 typedef const __attribute__((address_space(1))) float* gfptr;      // global address space: global_load, never flat_load
@@ -54,19 +56,22 @@ typedef const __attribute__((address_space(1))) int* giptr;
 typedef const __attribute__((address_space(1))) f32x4u* gf4ptr;
 
 template <class CFG, bool DIST, int K0, int K1 = -1, int K2 = -1, int K3 = -1, int K4 = -1>
-__global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args) {
+__global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs args) {
     constexpr bool VFOLD = K0 == MK_VFOLD;
     constexpr int DIST_SEG = VFOLD ? 1 : 2;              // the (dist | rank) segment: right after the one that streams v_o and v_k
     static_assert(!DIST || (VFOLD ? K1 == MK_PLAIN : (K1 == MK_GATHER_MUL && K2 == MK_PLAIN)), "DIST: v_o, v_k segment followed by the dist | rank segment");
     static_assert(!VFOLD || (CFG::BM == 48 && CFG::BN == 64 && CFG::WGM == 1 && CFG::WGN == 4 && CFG::DEPTH == 2) ||
-                            (CFG::BM == 96 && CFG::BN == 64 && CFG::WGM == 2 && CFG::WGN == 2 && CFG::DEPTH == 2 && !DIST), "fold: 48 x 64 or 96 x 64 tiles");
+                            (CFG::BM == 96 && CFG::BN == 64 && CFG::WGM == 2 && CFG::WGN == 2 && CFG::DEPTH == 2 && !DIST) ||
+                            (CFG::BM == 192 && CFG::BN == 64 && CFG::T == 512 && CFG::WGM == 4 && CFG::WGN == 2 && CFG::DEPTH == 2 && !DIST), "fold: 48 x 64, 96 x 64 or (8 waves) 192 x 64 tiles");
     constexpr int KS[6] = {K0, K1, K2, K3, K4, -1};
     constexpr int NSEG = K1 < 0 ? 1 : K2 < 0 ? 2 : K3 < 0 ? 3 : K4 < 0 ? 4 : 5;
     constexpr int BM = CFG::BM, BN = CFG::BN, BK = MF_BK, P = MF_P, DEPTH = CFG::DEPTH, BML = CFG::BM_LDS;
     constexpr int WTM = BM / CFG::WGM, WTN = BN / CFG::WGN, WM = WTM / 16, WN = WTN / 16, NSUB = BK / 8, NMF = 2 * WM * WN;
-    static_assert(CFG::WGM * CFG::WGN == 4 && WTM % 16 == 0 && WTN % 16 == 0 && BN % 32 == 0 && NSUB == 4, "tile");
-    // f32x4 per thread and k-step: thread t owns column quad t & 7 of tile rows (t >> 3) + 32 i
-    constexpr int NA = BML / 32, NB = BN / 32;
+    constexpr int MT = CFG::T, RP = CFG::RP;              // threads per workgroup; tile rows per loader pass
+    static_assert(CFG::WGM * CFG::WGN == MT / 64 && WTM % 16 == 0 && WTN % 16 == 0 && BN % RP == 0 && NSUB == 4, "tile");
+    static_assert(MT == 256 || !VFOLD || BM % 96 == 0, "the 48-row fold is a 256-thread form");
+    // f32x4 per thread and k-step: thread t owns column quad t & 7 of tile rows (t >> 3) + RP i
+    constexpr int NA = BML / RP, NB = BN / RP;
     extern __shared__ __attribute__((aligned(16))) float mf_smem[];
     float* const lds_a = mf_smem;                       // [2][BML][P]
     float* const lds_b = mf_smem + 2 * BML * P;         // [2][BN][P]
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
         constexpr int KIND = decltype(kind_c)::value;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int r = min(m0 + min(trow + 32 * i, BM - 1), M - 1);          // (rows beyond the tile / the matrix: clamped, never stored)
+            const int r = min(m0 + min(trow + RP * i, BM - 1), M - 1);          // (rows beyond the tile / the matrix: clamped, never stored)
             constexpr bool GAT = KIND == MK_GATHER || KIND == MK_GATHER_MUL;
             const long long row = GAT ? (long long)((giptr)g.idx)[r] : (long long)r;
             pa[i] = (gfptr)g.a + row * g.lda;
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
             lse[i] = KIND == MK_SOFTMAX ? ((gfptr)g.lse)[r] : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) pb[i] = (gfptr)g.b + (long long)min(n0 + trow + 32 * i, N - 1) * g.ldb;
+        for (int i = 0; i < NB; ++i) pb[i] = (gfptr)g.b + (long long)min(n0 + trow + RP * i, N - 1) * g.ldb;
     };
     // tile t of a segment -> register set S.  Operand side: 16-byte windows slid left to stay inside [0, klen) (klen % 4 == 0:
     // a window is either the true one or entirely beyond the extent, where the zero-padded weights null it); weight side:
@@ -202,12 +207,12 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[j], 1.44269504088896341f, -lse_c[i]));
                 }
-                *(f32x4*)(lds_a + buf * BML * P + (trow + 32 * i) * P + 4 * quad) = v;       // (rows >= BM: spare LDS rows, never read)
+                *(f32x4*)(lds_a + buf * BML * P + (trow + RP * i) * P + 4 * quad) = v;       // (rows >= BM: spare LDS rows, never read)
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 if (i + NA < h0 || i + NA >= h1) continue;
-                *(f32x4*)(lds_b + buf * BN * P + (trow + 32 * i) * P + 4 * quad) = vb[S][i];
+                *(f32x4*)(lds_b + buf * BN * P + (trow + RP * i) * P + 4 * quad) = vb[S][i];
             }
         };
         // prologue: tile t0 -> LDS buffer 0 (DEPTH 2: tile t0+2 into the freed set)
@@ -217,8 +222,8 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
                 float d2 = dacc[i];
                 d2 += __shfl_xor(d2, 1, 64); d2 += __shfl_xor(d2, 2, 64); d2 += __shfl_xor(d2, 4, 64);
                 dacc[i] = sqrtf(d2);
-                const int r = m0 + trow + 32 * i;
-                if (quad == 0 && tn == 0 && trow + 32 * i < BM && r < M) args.dist_out[(long long)r * args.ld_dist] = dacc[i];
+                const int r = m0 + trow + RP * i;
+                if (quad == 0 && tn == 0 && trow + RP * i < BM && r < M) args.dist_out[(long long)r * args.ld_dist] = dacc[i];
             }
             stash(S0{}, Tt{}, 0, 0, NA + NB);
         } else
@@ -446,36 +451,45 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
     //     b = fma(v_o[w][k], W_m[n][k], W_k[n][k])        (the same expression, hence the same bits, as the 48-row form)
     // 28.8 KB per workgroup and k-step for 64 MFMAs per wave, 512 workgroups = one round at two per CU.
     auto run_vfold4 = [&](const MainSeg& sg, const bool pf_next) __attribute__((always_inline)) {
-      if constexpr (VFOLD && BM == 96) {
-        constexpr int AR = 128, BR = 128;
+      if constexpr (VFOLD && BM % 96 == 0) {
+        constexpr int AR = 32 * (MT / 64), BR = 128;        // one 32-row A block per wave (= per triplet at K = 24)
+        constexpr int NAI = AR / RP, NBI = BR / RP, BH = 64 / RP;     // loader items per thread: A rows, W rows (BH of them W_k, BH W_m)
+        static_assert(NAI == 4 && BH >= 1, "fold loader");
         float* const fa = mf_smem;                          // [2][AR][P]   triplet w: rows 32 w .. 32 w + 23 = v_k, row 32 w + 24 = v_o[w]
         float* const fb = mf_smem + 2 * AR * P;             // [2][BR][P]   rows 0 .. 63 = W_k, 64 .. 127 = W_m (tile columns n0 ..)
         const int klen = sg.klen, nst = klen / BK;
         // kr = 24: four triplets, 32-row blocks (24 v_k rows, v_o, 7 spare); kr = 48 (K = 48): two triplets, 64-row blocks (48 v_k rows,
         // v_o, 15 spare) -- 4 MFMA row blocks per 48 rows against the 6 of the two plain segments, like 4 per 24 against 2 x 3
         const int kr = args.epi.rowdiv, blk = kr == 24 ? 32 : 64;
-        gfptr pA[4], pB[4];
+        gfptr pA[NAI], pB[NBI];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {                       // loader item i of this thread: A row trow + 32 i, B row trow + 32 i
-            const int lr = trow + 32 * i, tr = lr / blk, j = lr - tr * blk;     // LDS row -> (triplet of the tile, row of its block)
+        for (int i = 0; i < NAI; ++i) {                     // loader item i of this thread: A row trow + RP i
+            const int lr = trow + RP * i, tr = lr / blk, j = lr - tr * blk;     // LDS row -> (triplet of the tile, row of its block)
             const int r = min(m0 + kr * tr + (j < kr ? j : 0), M - 1);
             pA[i] = (gfptr)sg.a + (long long)(j < kr ? ((giptr)sg.idx)[r] : ((giptr)sg.idx2)[r]) * sg.lda;
-            const int n = min(n0 + trow + 32 * (i & 1), N - 1);
-            pB[i] = (gfptr)(i < 2 ? sg.b : sg.b2) + (long long)n * sg.ldb;
         }
-        f32x4 va4[2][4], vb4[2][4];
+#pragma unroll
+        for (int i = 0; i < NBI; ++i) {                     // ... and W row trow + RP i of [W_k (64 rows) ; W_m (64 rows)]
+            const int n = min(n0 + trow + RP * (i % BH), N - 1);
+            pB[i] = (gfptr)(i < BH ? sg.b : sg.b2) + (long long)n * sg.ldb;
+        }
+        f32x4 va4[2][NAI], vb4[2][NBI];
         auto vissue = [&](auto set_c, int t) __attribute__((always_inline)) {
             constexpr int SS_ = decltype(set_c)::value;
             const int c = min(t, nst - 1) * BK + 4 * quad;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { va4[SS_][i] = *(gf4ptr)(pA[i] + c); vb4[SS_][i] = *(gf4ptr)(pB[i] + c); }
+            for (int i = 0; i < NAI; ++i) va4[SS_][i] = *(gf4ptr)(pA[i] + c);
+#pragma unroll
+            for (int i = 0; i < NBI; ++i) vb4[SS_][i] = *(gf4ptr)(pB[i] + c);
         };
         auto vstash = [&](auto set_c, int buf, int part) __attribute__((always_inline)) {      // part 0: the A rows, part 1: W_k | W_m
             constexpr int SS_ = decltype(set_c)::value;
+            if (part == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (part == 0) *(f32x4*)(fa + buf * AR * P + (trow + 32 * i) * P + 4 * quad) = va4[SS_][i];
-                else           *(f32x4*)(fb + buf * BR * P + (trow + 32 * i) * P + 4 * quad) = vb4[SS_][i];
+                for (int i = 0; i < NAI; ++i) *(f32x4*)(fa + buf * AR * P + (trow + RP * i) * P + 4 * quad) = va4[SS_][i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < NBI; ++i) *(f32x4*)(fb + buf * BR * P + (trow + RP * i) * P + 4 * quad) = vb4[SS_][i];
             }
         };
         f32x4 acc4[2][4];
@@ -606,7 +620,7 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
         stamp(1 + I);
     };
     if constexpr (VFOLD) {
-        if constexpr (BM == 96) run_vfold4(args.seg[0], NSEG > 1);
+        if constexpr (BM % 96 == 0) run_vfold4(args.seg[0], NSEG > 1);
         else run_vfold(args.seg[0], NSEG > 1);
         base = nsteps[0]; started = true;
         stamp(1);
@@ -663,12 +677,12 @@ __global__ __launch_bounds__(MF_T, CFG::OCC) void k_main_fwd(const MainArgs args
         if (use_add) add_next = win(e.rowadd + (long long)(min(r, M - 1) / rdiv) * e.ld_rowadd, min(nl, max(N - 4, 0)), min(n, N - 1) - min(nl, max(N - 4, 0)));
     }
 #pragma unroll 1
-    for (int f = tid; f < BM * QR; f += MF_T) {
+    for (int f = tid; f < BM * QR; f += MT) {
         int r, n, nl;
         const int so = item(f, r, n, nl);
         const f32x4 addv = add_next;
-        if (use_add && f + MF_T < BM * QR) {
-            int r2, n2, nl2; item(f + MF_T, r2, n2, nl2);
+        if (use_add && f + MT < BM * QR) {
+            int r2, n2, nl2; item(f + MT, r2, n2, nl2);
             const int n2c = min(n2, N - 1), nl2c = min(nl2, n2c);
             add_next = win(e.rowadd + (long long)(min(r2, M - 1) / rdiv) * e.ld_rowadd, nl2c, n2c - nl2c);
         }
@@ -736,7 +750,7 @@ static inline int launch_main_fwd_seq(MainArgs& a, hipStream_t s) {
     const int tiles_m = (a.M + CFG::BM - 1) / CFG::BM, tiles_n = (a.N + CFG::BN - 1) / CFG::BN;
     const int S = a.split > 1 ? a.split : 1;
     const int grid = ((tiles_m * S + 7) / 8) * 8 * tiles_n;
-    hipLaunchKernelGGL((k_main_fwd<CFG, DIST, KINDS...>), dim3(grid), dim3(MF_T), lds, s, a);
+    hipLaunchKernelGGL((k_main_fwd<CFG, DIST, KINDS...>), dim3(grid), dim3(CFG::T), lds, s, a);
     NCX_HIP_TRY(hipGetLastError());
     if (S > 1) {
         const long long nthreads = (long long)a.M * ((a.N + 3) / 4);
@@ -767,7 +781,7 @@ static inline int launch_main_fwd(MainArgs& a, hipStream_t s) {
                 if (is({V, P, P, P})) return launch_main_fwd_seq<CFG, false, V, P, P, P>(a, s);
             }
         }
-        if constexpr (CFG::BM == 96 && CFG::BN == 64 && CFG::WGM == 2 && CFG::DEPTH == 2) {      // four triplets per workgroup (run_vfold4)
+        if constexpr (CFG::BM % 96 == 0 && CFG::BN == 64 && CFG::WGM * CFG::WGN == CFG::T / 64 && CFG::DEPTH == 2) {      // one triplet per wave (run_vfold4): 96 x 64 / 4 waves, 192 x 64 / 8 waves
             if (a.split > 1 || a.seg[0].klen % MF_BK || a.seg[0].klen < 2 * MF_BK || !a.epi.rowadd || (a.epi.rowdiv != 24 && a.epi.rowdiv != 48) || a.dist_out)
                 return NCX_E_FLAGS;
             if (is({V, P, P, S})) return launch_main_fwd_seq<CFG, false, V, P, P, S>(a, s);

@@ -9,6 +9,7 @@ typedef MainCfg<96, 128, 2, 2, 2, 1> MainCfg2;      // one workgroup per CU with
 typedef MainCfg<64, 64, 2, 2, 2, 3> MainCfg3;       // short chains (the answer-embedding gradient: 16 k-steps): three small workgroups per CU
 typedef MainCfg<48, 64, 1, 4, 2, 2> MainCfgFold;    // MK_VFOLD sequences: 48 x 64 tiles (two triplets), two workgroups per CU
 typedef MainCfg<96, 64, 2, 2, 2, 2> MainCfgFold4;   // MK_VFOLD sequences: 96 x 64 tiles (four triplets share the W_k | W_m tiles), two workgroups per CU
+typedef MainCfg<192, 64, 4, 2, 2, 2, 512> MainCfgFold8;   // MK_VFOLD on 192 x 64 tiles: ONE 8-wave workgroup per CU, eight triplets share the W_k | W_m tiles (experiment: NCX_FOLD8)
 
 // Measured inside the training step at configs[1] (B = 512: 256 tiles of 96 x 128): 338 us with one 96 x 128 workgroup per CU,
 // 346 / 348 us with two 48 x 128 / 96 x 64 workgroups per CU (on back-to-back launches of the kernel alone the order is the
@@ -16,11 +17,15 @@ typedef MainCfg<96, 64, 2, 2, 2, 2> MainCfgFold4;   // MK_VFOLD sequences: 96 x 
 // batches (data-parallel shards: 64 triplets per GPU) take the 48-row tile: twice the workgroups.
 int main_forward(MainArgs& a, hipStream_t s) {
     if (a.nseg > 0 && a.seg[0].kind == MK_VFOLD) {
-        // four triplets per workgroup when that still gives (nearly) two workgroups per CU; else two (twice the workgroups).
-        // Measured at configs[1] (tools/mb/mb_fold.hip, bit-identical outputs): 293 us against 318.
-        bool four = main_fold_rows(a.M, a.N) == 96 || a.epi.rowdiv == 48;      // (K = 48 exists on 96-row tiles only)
-        if (const char* f4 = hook_env("NCX_FOLD4")) four = atoi(f4) != 0;
-        return four ? launch_main_fwd<MainCfgFold4>(a, s) : launch_main_fwd<MainCfgFold>(a, s);
+        // One triplet per wave.  192 x 64 tiles = ONE 8-wave workgroup per CU (round 3: eight triplets share the W_k | W_m tiles, no
+        // old / young workgroup pair: 0.279-0.282 ms against 0.286-0.293 for two 96 x 64 workgroups per CU at configs[1], bit-identical);
+        // 96 x 64 = four triplets per workgroup, two workgroups per CU; 48 x 64 (two triplets) for small batches: twice the workgroups
+        // (tools/mb/mb_fold.hip, bit-identical outputs: 293 us against 318).
+        int rows = main_fold_rows(a.M, a.N);
+        if (a.epi.rowdiv == 48 && rows == 48) rows = 96;                       // (K = 48 exists on the one-triplet-per-wave forms only)
+        if (const char* f4 = hook_env("NCX_FOLD4")) rows = atoi(f4) != 0 ? 96 : (a.epi.rowdiv == 48 ? 96 : 48);
+        if (const char* f8 = hook_env("NCX_FOLD8")) rows = atoi(f8) != 0 ? 192 : (rows == 192 ? 96 : rows);
+        return rows == 192 ? launch_main_fwd<MainCfgFold8>(a, s) : rows == 96 ? launch_main_fwd<MainCfgFold4>(a, s) : launch_main_fwd<MainCfgFold>(a, s);
     }
     long long T = 0;
     for (int i = 0; i < a.nseg; ++i) T += (a.seg[i].klen + MF_BK - 1) / MF_BK;
@@ -35,8 +40,12 @@ int main_forward(MainArgs& a, hipStream_t s) {
 }
 
 int main_fold_rows(long long M, long long N) {
-    const long long wg96 = ((M + 95) / 96) * ((N + 63) / 64);
-    return wg96 * 4 >= (long long)num_cus() * 2 * 3 ? 96 : 48;          // >= 3/4 of the two-per-CU slots
+    const long long cus = num_cus();
+    const long long wg96 = ((M + 95) / 96) * ((N + 63) / 64), wg192 = ((M + 191) / 192) * ((N + 63) / 64);
+    if (wg96 * 4 < cus * 2 * 3) return 48;                                // < 3/4 of the two-per-CU slots: the 48-row form, twice the workgroups
+    // rounds of workgroup slots each form fills (192-row tiles: one 8-wave workgroup per CU; 96-row tiles: two 4-wave ones)
+    const double e8 = (double)wg192 / (double)(((wg192 + cus - 1) / cus) * cus), e4 = (double)wg96 / (double)(((wg96 + 2 * cus - 1) / (2 * cus)) * 2 * cus);
+    return e8 + 0.03 >= e4 ? 192 : 96;                                   // (the 8-wave form is ~3 % faster at equal fill)
 }
 
 int main_split(long long M, long long N, long long T) {

@@ -175,7 +175,8 @@ def plan_query(d, name):
     check(lib().ncx_plan_query(C.byref(d), GEMM_IDS[name], out), "ncx_plan_query")
     return dict(form=("NT", "TN", "NN")[out[0]], M=out[1], N=out[2], ksteps=out[3],
                 tile=("64x64", "128x128", "96x128", "96x64", "128x64", "48x128", "48x64 (per-triplet fold of the two v segments)",
-                      "96x64 (per-triplet fold of the two v segments, four triplets per workgroup)")[out[4]], ksplit=out[5])
+                      "96x64 (per-triplet fold of the two v segments, four triplets per workgroup)",
+                      "192x64 (per-triplet fold of the two v segments, eight triplets per 8-wave workgroup, one workgroup per CU)")[out[4]], ksplit=out[5])
 
 
 # ---- the C ABI's RCCL handle (include/neuralcx.h: ncx_comm_*, ncx_allreduce) ---------------------------------------------
