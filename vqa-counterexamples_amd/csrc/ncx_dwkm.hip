@@ -18,25 +18,28 @@
 
 namespace ncx {
 
-constexpr int KM_BN = 64, KM_PB = KM_BN + 16;   // LDS pitches = 16 mod 32: ds_read_b32 at its 2-cycle floor
+// LDS pitches = 16 mod 32: ds_read_b32 at its 2-cycle floor
 
 // K = rows per reduction step (a whole triplet, or a 24-row part of one: the rows of a step share v_o); Kc = candidates
 // per triplet, a multiple of K.
 // EDGE: some tile of the launch reaches beyond H or dv (16-byte windows slid left and repaired); interior launches compile
 // the repair out -- the reduction step is then ONE basic block (a branch in it costs ~15 %: ncx_main.h).
-template <int K, int KM_BM, int OCC, bool EDGE, int ABL = 0>
-__global__ __launch_bounds__(256, OCC) void k_dw_km(const float* __restrict__ dpre, int H, const float* __restrict__ feats, int dv,
+// T threads: 256 = 2 x 2 waves on a 128 (or 64) x 64 tile pair, two (four) workgroups per CU; 512 = 2 x 4 waves on a 128 x 128 tile pair, ONE
+// workgroup per CU (round 3: the dpre tile is shared by twice the columns, no old / young workgroup pair)
+template <int K, int KM_BM, int OCC, bool EDGE, int ABL = 0, int T = 256>
+__global__ __launch_bounds__(T, OCC) void k_dw_km(const float* __restrict__ dpre, int H, const float* __restrict__ feats, int dv,
                                                   const int* __restrict__ idx_k, const int* __restrict__ idx_o, int B, int Kc,
                                                   int chunk, int tiles_m, int S, float* __restrict__ slab) {
     extern __shared__ __attribute__((aligned(16))) float km_smem[];
-    constexpr int KM_PA = KM_BM + 16, QA = KM_BM / 4;   // (QA: 16-byte quads per A row)
-    constexpr int NA = (K * QA + 255) / 256, NB = (K * 16 + 255) / 256;
-    constexpr int KA = NA * 256 / QA, KB = NB * 16;     // tile rows incl. the ones only the unconditional stores touch
+    constexpr int KM_BN = T == 512 ? 128 : 64, KM_PB = KM_BN + 16, WGN = KM_BN / 32;
+    constexpr int KM_PA = KM_BM + 16, QA = KM_BM / 4, QB = KM_BN / 4;   // (QA, QB: 16-byte quads per A / B row)
+    constexpr int NA = (K * QA + T - 1) / T, NB = (K * QB + T - 1) / T;
+    constexpr int KA = NA * T / QA, KB = NB * T / QB;   // tile rows incl. the ones only the unconditional stores touch
     constexpr int a_elems = KA * KM_PA, b_elems = KB * KM_PB;
     float* const lds_a = km_smem;                       // [2][KA][KM_PA]
     float* const lds_b = km_smem + 2 * a_elems;         // [2][KB][KM_PB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
-    const int wm0 = (wave >> 1) * (KM_BM / 2), wn0 = (wave & 1) * 32;
+    const int wm0 = (wave / WGN) * (KM_BM / 2), wn0 = (wave % WGN) * 32;
     const int z = blockIdx.x % S, t = blockIdx.x / S;
     const int tm = t % tiles_m, tn = t / tiles_m;
     const int m0 = tm * KM_BM, n0 = tn * KM_BN;
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256, OCC) void k_dw_km(const float* __restrict__ dp
         const long long r0 = (long long)b * K;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int row = (tid + 256 * i) >> 4;
+            const int row = (tid + T * i) / QB;
             ix.k[i] = *(row < K ? idx_k + r0 + row : idx_o + r0);         // (idx_o is per row: any row of the step names its triplet's v_o)
         }
     };
@@ -79,12 +82,12 @@ __global__ __launch_bounds__(256, OCC) void k_dw_km(const float* __restrict__ dp
         const long long r0 = (long long)b * K;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int f = tid + 256 * i, row = min(f / QA, K - 1), c = m0 + 4 * (f % QA);
+            const int f = tid + T * i, row = min(f / QA, K - 1), c = m0 + 4 * (f % QA);
             ra[i] = EDGE ? load_window(dpre + (r0 + row) * H, c, H) : *(const f32x4u*)(dpre + (r0 + row) * H + c);   // (window repaired in stash)
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int f = tid + 256 * i, c = n0 + 4 * (f & 15);
+            const int f = tid + T * i, c = n0 + 4 * (f % QB);
             rb[i] = EDGE ? load_window(feats + (long long)ix.k[i] * dv, c, dv) : *(const f32x4u*)(feats + (long long)ix.k[i] * dv + c);
         }
         return keep;
@@ -92,15 +95,15 @@ __global__ __launch_bounds__(256, OCC) void k_dw_km(const float* __restrict__ dp
     auto stash = [&](const f32x4 (&ra)[NA], const f32x4 (&rb)[NB], int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int f = tid + 256 * i;
+            const int f = tid + T * i;
             const f32x4 v = EDGE ? fix_window(ra[i], m0 + 4 * (f % QA), H) : ra[i];
             *(f32x4*)(lds_a + buf * a_elems + (f / QA) * KM_PA + 4 * (f % QA)) = v;      // (rows >= K: copies of row K-1, never read)
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int f = tid + 256 * i;
-            const f32x4 v = EDGE ? fix_window(rb[i], n0 + 4 * (f & 15), dv) : rb[i];
-            *(f32x4*)(lds_b + buf * b_elems + (f >> 4) * KM_PB + 4 * (f & 15)) = v;
+            const int f = tid + T * i;
+            const f32x4 v = EDGE ? fix_window(rb[i], n0 + 4 * (f % QB), dv) : rb[i];
+            *(f32x4*)(lds_b + buf * b_elems + (f / QB) * KM_PB + 4 * (f % QB)) = v;
         }
     };
     constexpr int nk4 = K / 4;
@@ -142,16 +145,16 @@ __global__ __launch_bounds__(256, OCC) void k_dw_km(const float* __restrict__ dp
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if (i != it) continue;
-            const int f = tid + 256 * i;
+            const int f = tid + T * i;
             const f32x4 v = EDGE ? fix_window(ra[i], m0 + 4 * (f % QA), H) : ra[i];
             *(f32x4*)(lds_a + buf * a_elems + (f / QA) * KM_PA + 4 * (f % QA)) = v;      // (rows >= K: copies of row K-1, never read)
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             if (i + NA != it) continue;
-            const int f = tid + 256 * i;
-            const f32x4 v = EDGE ? fix_window(rb[i], n0 + 4 * (f & 15), dv) : rb[i];
-            *(f32x4*)(lds_b + buf * b_elems + (f >> 4) * KM_PB + 4 * (f & 15)) = v;
+            const int f = tid + T * i;
+            const f32x4 v = EDGE ? fix_window(rb[i], n0 + 4 * (f % QB), dv) : rb[i];
+            *(f32x4*)(lds_b + buf * b_elems + (f / QB) * KM_PB + 4 * (f % QB)) = v;
         }
     };
     constexpr int NBLK = WM * WN, NIT = NA + NB;
@@ -331,16 +334,31 @@ int dw_km(const ncx_dims& d, const float* dpre, const float* feats, const int* i
     // 128-row tiles at two workgroups per CU, or 64-row tiles at four (hook NCX_KM_BM=64)
     int bm = 128;
     if (const char* e = hook_env("NCX_KM_BM")) bm = atoi(e) == 64 ? 64 : 128;
-    const int tiles_m = (d.H + bm - 1) / bm, tiles_n = (d.dv + KM_BN - 1) / KM_BN;
-    const bool edge = d.H % bm != 0 || d.dv % KM_BN != 0;
+    // 128 x 128 tile pairs as ONE 8-wave workgroup per CU (what gave the forward kernel 3 %): measured here 124.8 us against 123.7 for
+    // two 4-wave workgroups per CU (DW1C 0.3231 / 0.3233 against 0.3215 / 0.3220 ms) -- kept behind the hook NCX_KM_T=512 only
+    bool wide = false;
+    if (const char* e = hook_env("NCX_KM_T")) wide = atoi(e) == 512 && bm == 128;
+    const int bn = wide ? 128 : 64;
+    const int tiles_m = (d.H + bm - 1) / bm, tiles_n = (d.dv + bn - 1) / bn;
+    const bool edge = d.H % bm != 0 || d.dv % bn != 0;
     auto go = [&](auto bm_c, auto occ_c, auto edge_c) -> int {
         constexpr int BM = decltype(bm_c)::value, OCC = decltype(occ_c)::value;
         constexpr bool EDGE = decltype(edge_c)::value;
         constexpr int QA = BM / 4, NA = (R * QA + 255) / 256, KA = NA * 256 / QA, KB = (R * 16 + 255) / 256 * 16;
-        const int lds = 2 * (KA * (BM + 16) + KB * KM_PB) * 4;
+        const int lds = 2 * (KA * (BM + 16) + KB * (64 + 16)) * 4;
         static DevMask attr{0};
         NCX_HIP_TRY(set_max_lds_once(attr, (const void*)k_dw_km<R, BM, OCC, EDGE>, lds));
         hipLaunchKernelGGL((k_dw_km<R, BM, OCC, EDGE>), dim3(tiles_m * tiles_n * S), dim3(256), lds, s, dpre, d.H, feats, d.dv, idx_k, idx_o, d.B, d.K,
+                           chunk, tiles_m, S, slab);
+        return (int)hipGetLastError();
+    };
+    auto go8 = [&](auto edge_c) -> int {                   // 512 threads, 128 x 128 tile pair
+        constexpr bool EDGE = decltype(edge_c)::value;
+        constexpr int T = 512, QA = 32, QB = 32, NA = (R * QA + T - 1) / T, NB = (R * QB + T - 1) / T, KA = NA * T / QA, KB = NB * T / QB;
+        const int lds = 2 * (KA * (128 + 16) + KB * (128 + 16)) * 4;
+        static DevMask attr{0};
+        NCX_HIP_TRY(set_max_lds_once(attr, (const void*)k_dw_km<R, 128, 2, EDGE, 0, T>, lds));
+        hipLaunchKernelGGL((k_dw_km<R, 128, 2, EDGE, 0, T>), dim3(tiles_m * tiles_n * S), dim3(T), lds, s, dpre, d.H, feats, d.dv, idx_k, idx_o, d.B, d.K,
                            chunk, tiles_m, S, slab);
         return (int)hipGetLastError();
     };
@@ -349,8 +367,9 @@ int dw_km(const ncx_dims& d, const float* dpre, const float* feats, const int* i
     int rc;
     int abl = 0;
     if (const char* e = hook_env("NCX_KM_ABL")) abl = atoi(e);
-    if (abl >= 1 && abl <= 4 && !edge && bm == 128) {        // timing ablations (results are wrong): 1 no barrier, 2 no global loads, 3 no LDS stores, 4 no fold
-        const int lds = 2 * (24 * (128 + 16) + 32 * KM_PB) * 4;
+    if (wide) rc = edge ? go8(std::true_type{}) : go8(std::false_type{});
+    else if (abl >= 1 && abl <= 4 && !edge && bm == 128) {        // timing ablations (results are wrong): 1 no barrier, 2 no global loads, 3 no LDS stores, 4 no fold
+        const int lds = 2 * (24 * (128 + 16) + 32 * (64 + 16)) * 4;
         auto run = [&](auto abl_c) -> int {
             constexpr int A = decltype(abl_c)::value;
             NCX_HIP_TRY(hipFuncSetAttribute((const void*)k_dw_km<R, 128, 2, false, A>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
