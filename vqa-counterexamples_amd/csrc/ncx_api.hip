@@ -19,15 +19,24 @@ namespace ncx {
 // =================================================================================================
 // small kernels
 // =================================================================================================
+// Wave-wide reductions on the DPP network (round 3).  __shfl_xor compiles to ds_bpermute_b32 + s_waitcnt: six dependent LDS round
+// trips per reduction -- k_train_tail's 24 row dots were 187 of them, ~9 of the kernel's 16 us.  Here: four DPP steps inside each row
+// of 16 lanes (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: every lane then holds its row's result), then the four
+// row results through v_readlane.  Fixed association ((quad pairs) half rows) rows: deterministic, the same in every kernel that
+// calls it (the fused and unfused paths stay bit-identical to each other).
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
+    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_mov<0xB1>(v)); v = fmaxf(v, dpp_mov<0x4E>(v)); v = fmaxf(v, dpp_mov<0x141>(v)); v = fmaxf(v, dpp_mov<0x140>(v));
+    return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
 }
 
 // One wave per logical row r = b*K + k.  4 rows per 256-thread block.
@@ -507,17 +516,21 @@ __global__ __launch_bounds__(256) void k_bwd_prelude_finish(const float* __restr
 //   dpre, dSh, partial sums of d out.weight / d out.bias / d linear_1.bias   (k_bwd_prelude, same wave partition)
 // Same per-lane arithmetic and the same wave reductions as the three kernels it replaces: scores, loss, ranks and every
 // gradient except d out.bias (a sum of zeros-in-maths; other order) are bit-identical to the unfused path.
-template <int KB>
+// FULL: H == 256 and K == KB exactly (every lane owns 4 in-range columns, every row slot a real row): the edge handling -- a branch per store, a repair per load -- is compiled
+// out; the kernel is ONE wave's instruction stream per triplet and runs as long as that stream is (round 3: 5 100 -> see DESIGN 7)
+template <int KB, bool FULL>
 __global__ __launch_bounds__(64) void k_train_tail(const float* __restrict__ h, const float* __restrict__ w_out,
                                                     const float* __restrict__ b_out, const int* __restrict__ gt, int B, int K, int H,
                                                     float loss_scale, float gate_scale, float* __restrict__ scores,
                                                     float* __restrict__ loss_rows, float* __restrict__ dscores, int* __restrict__ rank,
                                                     float* __restrict__ dpre, float* __restrict__ dsh,
                                                     float* __restrict__ partial_w, float* __restrict__ partial_b1,
-                                                    float* __restrict__ partial_b, float* __restrict__ zero_buf, long long zero_n) {
+                                                    float* __restrict__ partial_b, float* __restrict__ zero_buf, long long zero_n, int zchunk) {
+    if (FULL) { H = 256; K = KB; }                          // (compile-time extents: row addresses become base + constant, no clamps)
     const int blk = blockIdx.x, nblk = gridDim.x;
-    if (zero_buf) {          // (as k_bwd_prelude: dGgt is scattered into zeros later in the backward)
-        const long long z0 = zero_n * blk / nblk / 4 * 4, z1 = blk + 1 == nblk ? zero_n : zero_n * (blk + 1) / nblk / 4 * 4;
+    if (zero_buf) {          // (as k_bwd_prelude: dGgt is scattered into zeros later in the backward; zchunk = ceil(zero_n / nblk) up to a
+                             // multiple of 4, from the host: a 64-bit division here is ~300 scalar instructions of a 2 400-instruction kernel)
+        const long long z0 = (long long)blk * zchunk, z1 = min(z0 + zchunk, zero_n);
         for (long long i = z0 + 4 * threadIdx.x; i < z1; i += 256) {
             if (i + 3 < z1) *(f32x4u*)(zero_buf + i) = f32x4{0.f, 0.f, 0.f, 0.f};
             else for (long long j = i; j < z1; ++j) zero_buf[j] = 0.f;
@@ -525,14 +538,14 @@ __global__ __launch_bounds__(64) void k_train_tail(const float* __restrict__ h, 
     }
     const int lane = threadIdx.x;                           // one wave per block: 512 triplets spread over all CUs, not 128 of them
     const int wv = blk, nwv = nblk;
-    const int b0 = (int)((long long)B * wv / nwv), b1 = (int)((long long)B * (wv + 1) / nwv);
+    const int b0 = (int)((unsigned)B * (unsigned)wv / (unsigned)nwv), b1 = (int)((unsigned)B * (unsigned)(wv + 1) / (unsigned)nwv);   // (B * nwv < 2^32: B <= 32768, nwv <= 4096)
     const int c = lane * 4;
-    const bool live = c < H, edge = c + 4 > H;
+    const bool live = FULL || c < H, edge = !FULL && c + 4 > H;
     auto put4 = [&](float* p, const f32x4& v) __attribute__((always_inline)) {
-        if (c + 3 < H) *(f32x4u*)(p + c) = v;
+        if (FULL || c + 3 < H) *(f32x4u*)(p + c) = v;
         else if (live) { p[c] = v[0]; if (c + 1 < H) p[c + 1] = v[1]; if (c + 2 < H) p[c + 2] = v[2]; }
     };
-    const f32x4 w = fix_window(load_window(w_out, c, H), c, H);          // (lanes beyond H: all zeros)
+    const f32x4 w = FULL ? *(const f32x4u*)(w_out + c) : fix_window(load_window(w_out, c, H), c, H);          // (lanes beyond H: all zeros)
     const float bias = b_out[0];
     f32x4 aw = {0.f, 0.f, 0.f, 0.f}, ab1 = {0.f, 0.f, 0.f, 0.f};
     float sb = 0.f;
@@ -540,7 +553,7 @@ __global__ __launch_bounds__(64) void k_train_tail(const float* __restrict__ h, 
         const long long r0 = (long long)b * K;
         f32x4 hv[KB];
 #pragma unroll
-        for (int k = 0; k < KB; ++k) hv[k] = load_window(h + (r0 + min(k, K - 1)) * H, c, H);
+        for (int k = 0; k < KB; ++k) hv[k] = FULL ? *(const f32x4u*)(h + (r0 + min(k, K - 1)) * H + c) : load_window(h + (r0 + min(k, K - 1)) * H, c, H);
         const int g = gt[b];
         if (edge) {
 #pragma unroll
@@ -1364,9 +1377,11 @@ int ncx_train_tail(const ncx_dims* dp, const ncx_params* p, void* workspace, siz
     float* dsh = fuse_l1 ? (float*)(ws + w.dsh) : (float*)nullptr;
     float* zb = emb_nt ? dagtT : aemb ? dagt : (float*)nullptr;
     const long long zn = emb_nt ? (long long)d.A * Hp4 : (long long)H * d.A;
-#define NCX_TAIL_LAUNCH(KB) hipLaunchKernelGGL(k_train_tail<KB>, dim3(nblk * 4), dim3(64), 0, s, hL, p->w_out, p->b_out, gt, d.B, d.K, H, scale, dscale, \
-                                               scores, loss_rows, dscores, rank, dpre, dsh, part_w, part_b1, part_b, zb, zn)
-    if (d.K <= 8) NCX_TAIL_LAUNCH(8); else if (d.K <= 16) NCX_TAIL_LAUNCH(16); else if (d.K <= 24) NCX_TAIL_LAUNCH(24); else NCX_TAIL_LAUNCH(32);
+#define NCX_TAIL_LAUNCH(KB, FULL) hipLaunchKernelGGL((k_train_tail<KB, FULL>), dim3(nblk * 4), dim3(64), 0, s, hL, p->w_out, p->b_out, gt, d.B, d.K, H, scale, dscale, \
+                                               scores, loss_rows, dscores, rank, dpre, dsh, part_w, part_b1, part_b, zb, zn, zchunk)
+    const int zchunk = (int)((cdiv(zn, (long long)nblk * 4) + 3) / 4 * 4);
+    if (H == 256 && d.K == 24) NCX_TAIL_LAUNCH(24, true);          // (the configuration of every options/cx/*.yaml with dim_h 256)
+    else if (d.K <= 8) NCX_TAIL_LAUNCH(8, false); else if (d.K <= 16) NCX_TAIL_LAUNCH(16, false); else if (d.K <= 24) NCX_TAIL_LAUNCH(24, false); else NCX_TAIL_LAUNCH(32, false);
 #undef NCX_TAIL_LAUNCH
     NCX_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_bwd_prelude_finish, dim3((unsigned)cdiv(H, 8), 3), dim3(256), 0, s, (const float*)part_w, (const float*)part_b1,
