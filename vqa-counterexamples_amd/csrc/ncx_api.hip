@@ -489,8 +489,18 @@ __global__ __launch_bounds__(256) void k_bwd_prelude_finish(const float* __restr
     float* out = which == 0 ? out_w : out_b1;
     if (!out) return;
     const int n = blockIdx.x * 8 + c;
+    // the partial rows of this thread (ch = g, g + 32, ...) are requested 16 at a time before the first is added: a load per
+    // iteration of the runtime-length loop was one dependent round trip per row (16 of them = the kernel's 7 us); same order of adds
     float s = 0.f;
-    if (n < H) for (int ch = g; ch < nblk; ch += 32) s += part[(long long)ch * H + n];
+    if (n < H) {
+        for (int ch0 = g; ch0 < nblk; ch0 += 32 * 16) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { const int ch = ch0 + 32 * i; v[i] = part[(long long)min(ch, nblk - 1) * H + n]; }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s += ch0 + 32 * i < nblk ? v[i] : 0.f;
+        }
+    }
     red[g][c] = s;
     __syncthreads();
     if (g == 0 && n < H) {
