@@ -10,7 +10,10 @@
  *
  * Conventions
  *   - plain C: raw DEVICE pointers + sizes + a HIP stream (hipStream_t passed as void*); no
- *     torch types, no exceptions, no allocation inside, no global state.  The caller owns every
+ *     torch types, no exceptions, no allocation inside, no global state on the product path (the
+ *     only process-level state is the OPT-IN diagnostics at the end of this file -- ncx_profile_begin /
+ *     _end and ncx_profile_stamps, the latter keyed by device -- and the lazily created per-device
+ *     side stream, off unless NCX_SIDE_STREAM is set).  The caller owns every
  *     buffer (PyTorch's caching allocator in the shipped binding) and must keep them alive until
  *     the enqueued work has completed.
  *   - all floating point data is fp32, contiguous row-major; indices are int32.
@@ -273,7 +276,8 @@ int ncx_profile_end(float* ms, int32_t* ids, int32_t cap);
  * word 0 = shader-cycle counter (s_memtime) at kernel entry, word 8 = the same at exit, words 14 / 15 = the 100 MHz
  * constant-rate counter (s_memrealtime) at entry / exit, word 13 = XCC id.  The clock a workgroup held is
  * (w8 - w0) / (w15 - w14) x 100 MHz.  `words` = capacity of the device buffer in uint64 (>= 16 x workgroups of the
- * launch, else the launch is not stamped).  ncx_profile_stamps(NULL, 0) disarms.  The timed product path never arms it
+ * launch, else the launch is not stamped).  Armed for the CURRENT device only (the buffer lives there; forwards on other
+ * devices of the process never see it); ncx_profile_stamps(NULL, 0) disarms it.  The timed product path never arms it
  * (bench.py stamps a separate diagnostic pass after its timed region). */
 int ncx_profile_stamps(unsigned long long* stamps, int64_t words);
 /* out6 = {form (0 NT,1 TN,2 NN), M, N, 32-deep k-steps, tile cfg (0 64x64, 1 128x128, 2 96x128, 3 96x64, 4 128x64; the fused forward

@@ -59,6 +59,11 @@ def test_forward_without_gpu_fails_loudly():
     m = NeuralModel(model_spec=spec, dim_h=16, n_layers=1, emb=None, drop_p=0.0, vqa_model=vqa, knn_size=24, trainable_vqa=False)
     with pytest.raises(NcxError):
         m(torch.rand(2, 25, 64), torch.ones(2, 26, dtype=torch.long), torch.zeros(2, dtype=torch.long))
+    # nn.Embedding's IndexError for an answer id outside the vocabulary (cx.py:280): on a CPU device the check is immediate
+    # (the deferred, sync-free form exists for the GPU only), and it comes before the device error
+    with pytest.raises(IndexError):
+        m(torch.rand(2, 25, 64), torch.ones(2, 26, dtype=torch.long), torch.full((2,), 20, dtype=torch.long))
+    m.eval(); m.train(); m.state_dict()                    # nothing pending: mode switches and state_dict() stay silent
 
 
 def test_update_values_semantics():

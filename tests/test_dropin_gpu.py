@@ -607,6 +607,21 @@ def test_module_is_reentrant_two_forwards_before_backward():
         torch.cuda.synchronize()
     assert raised == 1
     m(ia[0], ia[1], ia[2]); m.check_answer_ids()                   # and the flag clears once reported
+    # a bad id in the LAST forward of an epoch / evaluation pass cannot be scored silently and then checkpointed: the deferred
+    # verdict is collected by every mode switch and by state_dict() (the reference's loop does both: counterexamples.py:320,451,555)
+    m(ia[0], ia[1], torch.full_like(ia[2], A))
+    with pytest.raises(IndexError):
+        m.eval()
+    m(ia[0], ia[1], torch.full_like(ia[2], A))
+    with pytest.raises(IndexError):
+        m.state_dict()
+    m.train(); m.state_dict()                                      # reported once, then clear
+    # strict_ids: nn.Embedding's behaviour exactly -- the offending call raises, nothing is launched
+    m.strict_ids = True
+    with pytest.raises(IndexError):
+        m(ia[0], ia[1], torch.full_like(ia[2], A))
+    m.check_answer_ids(); m(ia[0], ia[1], ia[2])
+    m.strict_ids = False
 
 
 def test_cli_resume_continues_bit_for_bit(tmp_path, capsys):

@@ -13,6 +13,7 @@
 #include "ncx_bf16.h"
 #include <stdlib.h>
 #include <stdio.h>
+#include <atomic>
 
 namespace ncx {
 
@@ -1052,8 +1053,19 @@ static int check_dims(const ncx_dims* d) {
 // -------------------------------------------------------------------------------------------------
 struct ProfState { bool on; unsigned mask; int n, cap; hipEvent_t* ev; int* ids; };
 static ProfState g_prof = {false, 0u, 0, 0, nullptr, nullptr};
-static unsigned long long* g_stamps = nullptr;      // ncx_profile_stamps: in-kernel clock stamps of MAIN (diagnostic passes only)
-static long long g_stamp_words = 0;
+// ncx_profile_stamps: in-kernel clock stamps of MAIN (diagnostic passes only).  One slot per DEVICE, like side_stream()'s table: the
+// buffer is a device pointer, so a forward on another GPU of the same process must never see it; pointer and capacity are published
+// together (the capacity is written first, the pointer last, and read in the opposite order) so a concurrent forward sees either
+// the old pair or the new one.
+struct StampSlot { std::atomic<unsigned long long*> ptr; std::atomic<long long> words; };
+static StampSlot g_stamps[16];
+static inline unsigned long long* stamps_for_current_device(long long need_words) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return nullptr; }
+    unsigned long long* p = g_stamps[dev].ptr.load(std::memory_order_acquire);
+    if (!p || g_stamps[dev].words.load(std::memory_order_acquire) < need_words) return nullptr;
+    return p;
+}
 
 static int run_gemm_impl(GemmArgs& a, int form, const GemmPlan& pl, float* slab, size_t slab_bytes,
                          const float* reduce_bias, hipStream_t s);
@@ -1276,7 +1288,7 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
             a.split = main_split(M, H, T); a.slab = (float*)(ws + w.mslab);
             if (a.split > 1 && (size_t)a.split * M * H * 4 > w.mslab_bytes) return NCX_E_WORKSPACE;
         }
-        if (g_stamps && a.split <= 1 && (long long)(((M + 47) / 48 + 7) / 8 * 8) * ((H + 63) / 64) * 16 <= g_stamp_words) a.stamps = g_stamps;   // (bound: the smallest tile = the most workgroups)
+        if (a.split <= 1) a.stamps = stamps_for_current_device((long long)(((M + 47) / 48 + 7) / 8 * 8) * ((H + 63) / 64) * 16);   // (bound: the smallest tile = the most workgroups; null unless armed on THIS device)
         rc = prof_open(U_MAIN, s); if (rc) return rc;
         rc = main_forward(a, s); if (rc) return rc;
         rc = prof_close(U_MAIN, s); if (rc) return rc;
@@ -1834,7 +1846,13 @@ int ncx_profile_end(float* ms, int32_t* ids, int32_t cap) {
 
 int ncx_profile_stamps(unsigned long long* stamps, int64_t words) {
     if ((stamps == nullptr) != (words == 0) || words < 0) return NCX_E_DIMS;
-    g_stamps = stamps; g_stamp_words = words;
+    int dev = 0;
+    NCX_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return NCX_E_DIMS;
+    // armed for the CURRENT device only (the buffer lives there); disarm = pointer first, so no reader pairs the old pointer with 0 words
+    if (!stamps) { g_stamps[dev].ptr.store(nullptr, std::memory_order_release); g_stamps[dev].words.store(0, std::memory_order_release); }
+    else { g_stamps[dev].ptr.store(nullptr, std::memory_order_release); g_stamps[dev].words.store(words, std::memory_order_release);
+           g_stamps[dev].ptr.store(stamps, std::memory_order_release); }
     return NCX_OK;
 }
 

@@ -13,7 +13,12 @@ Deliberate differences from the reference (all supersets):
   * knn_size may be 1..64 (the reference asserts == 24, cx.py:226); config 5 of BASELINE.json uses 48;
   * `trainable_vqa=True` is rejected (input gradients are not produced; the reference's default and every
     options/cx/*.yaml use a frozen VQA model, cx.py:73-80);
-  * lesion combination q_emb=z_emb=False with a_emb=True raises a clear error (NameError in the reference).
+  * lesion combination q_emb=z_emb=False with a_emb=True raises a clear error (NameError in the reference);
+  * an answer id outside [0, ans_size) raises IndexError like nn.Embedding (cx.py:280), but by default NOT at the offending
+    call: the verdict is read without a host sync and surfaces at the next point that syncs anyway -- the next forward
+    whose flag copy has landed, `train()` / `eval()` (the reference switches modes around every evaluation and epoch),
+    `state_dict()` (every checkpoint save), or `check_answer_ids()`.  `strict_ids=True` (constructor keyword or attribute)
+    restores the immediate raise at the price of one host sync per forward; on a CPU device the check is always immediate.
 """
 import torch
 import torch.nn as nn
@@ -149,6 +154,7 @@ class NeuralModel(CXModelBase):
         self._pool = ops.WorkspacePool()
         self._step = 0
         self.dropout_seed = 42
+        self.strict_ids = bool(kwargs.get("strict_ids", False))     # True: bad answer ids raise at the offending forward (host sync)
 
     # ---- the HIP hot path ---------------------------------------------------------------------------------
     def _param_fields(self):
@@ -195,6 +201,18 @@ class NeuralModel(CXModelBase):
             self._aid_flag.zero_()                                  # (sticky on the device until reported)
             raise IndexError("answer_aids outside [0, %d) in a previous forward" % self.ans_size)
 
+    # The deferred verdict is collected wherever the caller synchronises anyway: a mode switch (the reference calls
+    # cx_model.eval() / .train() around eval_model and at every epoch, counterexamples.py:320,451) and state_dict() (checkpoint
+    # save, counterexamples.py:555) -- so a bad id in the last forward of an epoch or of an evaluation pass cannot be scored
+    # silently and then checkpointed.
+    def train(self, mode=True):
+        self.check_answer_ids(wait=True)
+        return super().train(mode)
+
+    def state_dict(self, *args, **kwargs):
+        self.check_answer_ids(wait=True)
+        return super().state_dict(*args, **kwargs)
+
     def forward(self, image_features, question_wids, answer_aids):
         spec = self.model_spec
         B = image_features.size(0)
@@ -226,6 +244,8 @@ class NeuralModel(CXModelBase):
             # copy of step n has usually not landed when step n + 1 is enqueued, and a later copy must still carry step n's verdict.
             self.check_answer_ids(wait=False)
             bad = ((answer_aids < 0) | (answer_aids >= self.ans_size)).any().view(1)
+            if (self.strict_ids or dev.type != "cuda") and bool(bad):      # immediate raise, before anything is launched
+                raise IndexError("answer_aids outside [0, %d)" % self.ans_size)
             answer_aids = answer_aids.clamp(0, self.ans_size - 1)
             if self._aid_host is None or self._aid_flag is None or self._aid_flag.device != dev:
                 self._aid_host = torch.zeros(1, dtype=torch.bool).pin_memory() if dev.type == "cuda" else torch.zeros(1, dtype=torch.bool)
