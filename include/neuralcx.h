@@ -134,6 +134,21 @@ size_t ncx_workspace_bytes(const ncx_dims* d);
 int ncx_forward(const ncx_dims* d, const ncx_inputs* in, const ncx_params* p,
                 void* workspace, size_t workspace_bytes, float* scores, void* stream);
 
+/* The same forward cut where the data ends and the weights begin (net-new; the reference is single-GPU: the cut exists for
+ * the data-parallel step, counterexamples.py:334-339 being where a DP job sums gradients):
+ *   NCX_FWD_PRELUDE  everything that is a function of the batch alone -- the feature-table row ids of every candidate row,
+ *                    the pairwise distance (cx.py:300), the rank one-hot (cx.py:304-305), the softmax statistics of the
+ *                    answer logits (cx.py:281); in the bf16 variant also the packed candidate rows.  Reads no weight
+ *                    (`p` is validated like in ncx_forward but not dereferenced on the device; `scores` may be NULL).
+ *   NCX_FWD_REST     everything that reads the weights (padded weight copies, Gt, Sh, linear_1..3, out).
+ * PRELUDE then REST == ncx_forward bit for bit, on the same workspace.  A DP job enqueues step n + 1's PRELUDE before it waits
+ * for step n's last gradient bucket and applies that bucket's Adam slice: the exchange hides under it. */
+#define NCX_FWD_ALL     0
+#define NCX_FWD_PRELUDE 1
+#define NCX_FWD_REST    2
+int ncx_forward_phase(const ncx_dims* d, const ncx_inputs* in, const ncx_params* p,
+                      void* workspace, size_t workspace_bytes, float* scores, int32_t phase, void* stream);
+
 /* Replaces nn.CrossEntropyLoss(size_average=False)(scores, comp_idxs) / len(batch)
  * (counterexamples.py:310,334) and recallAtK (counterexamples.py:501-506) in one pass.
  *   loss_rows[B]  per-triplet CE * scale          (nullable)

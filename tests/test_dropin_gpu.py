@@ -395,6 +395,7 @@ def _dp_gpu_worker(rank, world, port, q, bf16=False):
     sub = {k: v[ids] for k, v in batch.items()}
     b = ops.Batch.from_dense(*[sub[k].to(DEV) for k in ("image_features", "q_emb", "z_orig", "z_knns", "a_knns", "answer_aids")])
     r = eng.train_step(b, sub["gt"].to(DEV).to(torch.int32), global_batch=Bg)
+    eng.flush()                                                     # (the last gradient bucket's wait + Adam slice are deferred: engine.pipeline)
     torch.cuda.synchronize()
     loss = torch.tensor([float(r["loss"])], dtype=torch.float64)
     dist.all_reduce(loss)                                           # sum of the 1/B_global-scaled local losses
@@ -655,6 +656,71 @@ def test_cli_resume_continues_bit_for_bit(tmp_path, capsys):
     cli.main(common + ["--epochs", "3", "--project_dir", d_res, "--resume", run])
     assert "Epoch 3 val: loss:" in capsys.readouterr().out
     assert len(torch.load(os.path.join(base, "info.ckpt"))) == 3
+
+
+def _dp_pipeline_worker(rank, world, port, q, pipeline):
+    import os, sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from conftest import PKG, ROOT
+    sys.path[:0] = [ROOT, PKG, os.path.join(ROOT, "tests")]
+    import torch.distributed as dist
+    from neuralcx import dp, ops
+    from neuralcx.engine import NeuralCXEngine
+    dp.init_distributed(backend="gloo")
+    d = orc.Dims(dv=96, dq=64, dz=24, A=40, H=64, L=1)
+    Bg, steps = 12, 5
+    batch = _dp_batch(d, Bg * steps)
+    eng = NeuralCXEngine(K=d.K, dv=d.dv, dq=d.dq, dz=d.dz, da=d.da, A=d.A, H=d.H, L=d.L, drop_p=0.25, lr=1e-3, device=DEV, world_size=world)
+    eng.rank = rank
+    eng.pipeline = pipeline
+    eng.load_state(orc.init_params(d, seed=4, gain=2.0))
+    losses, deferred = [], 0
+    for s_ in range(steps):
+        ids = [s_ * Bg + i for i in dp.shard(list(range(Bg)), rank, world)]
+        sub = {k: v[ids] for k, v in batch.items()}
+        b = ops.Batch.from_dense(*[sub[k].to(DEV) for k in ("image_features", "q_emb", "z_orig", "z_knns", "a_knns", "answer_aids")])
+        r = eng.train_step(b, sub["gt"].to(DEV).to(torch.int32), global_batch=Bg)
+        deferred += eng._pending is not None
+        losses.append(float(r["loss"]))
+        if s_ == 2:                                                 # an evaluation between two steps reads the FINAL weights of step 3
+            losses.append(float(eng.eval_step(b, sub["gt"].to(DEV).to(torch.int32))["loss"]))
+    out = {k: v.cpu().numpy() for k, v in eng.state_dict().items()}
+    torch.cuda.synchronize()
+    st = eng.optimizer_state()
+    out["__exp_avg__"] = st["exp_avg"].numpy(); out["__exp_avg_sq__"] = st["exp_avg_sq"].numpy()
+    out["__losses__"] = np.asarray(losses); out["__rank__"] = rank; out["__deferred__"] = deferred
+    q.put(out)
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_dp2_pipelined_bucket2_is_bit_identical_to_the_unpipelined_engine():
+    """engine.pipeline (round 4): under data parallelism the wait for the LAST gradient bucket and the Adam slice it feeds are
+    deferred to the next train_step, behind that step's data-only forward prelude (ncx_forward_phase PRELUDE: k_prep), so the
+    exchange has the prelude to hide behind.  Same kernels, same operands, every dependency respected: after 5 steps with
+    dropout on two ranks (gloo on one card) the weights, both Adam moments, every per-step loss and an evaluation taken between
+    two steps are BIT-identical to the unpipelined engine's, and the replicas are identical."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    res = {}
+    for pipeline in (True, False):
+        q = ctx.Queue()
+        port = 29400 + os.getpid() % 200 + int(pipeline)
+        procs = [ctx.Process(target=_dp_pipeline_worker, args=(r, 2, port, q, pipeline)) for r in range(2)]
+        [p.start() for p in procs]
+        outs = [q.get(timeout=240), q.get(timeout=240)]
+        [p.join(120) for p in procs]
+        assert all(p.exitcode == 0 for p in procs)
+        outs.sort(key=lambda o: o["__rank__"])
+        for k in outs[0]:
+            if not k.startswith("__") or k in ("__exp_avg__", "__exp_avg_sq__"):
+                assert np.array_equal(outs[0][k], outs[1][k]), (pipeline, k)          # replicas identical
+        assert outs[0]["__deferred__"] == (5 if pipeline else 0)                        # (the deferral really happened / really did not)
+        res[pipeline] = outs
+    for rank in (0, 1):
+        a, b = res[True][rank], res[False][rank]
+        for k in a:
+            if k not in ("__rank__", "__deferred__"):
+                assert np.array_equal(a[k], b[k]), (rank, k)
 
 
 def _dp_idle_rank_worker(rank, world, port, q):

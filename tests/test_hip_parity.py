@@ -467,6 +467,45 @@ def test_one_train_step_matches_golden_adam():
         # gradients are of the order of eps = 1e-8 themselves sit in Adam's linear regime and the bound follows f's slope there)
 
 
+@pytest.mark.parametrize("shape", ["ragged_small", "configs1", "bf16"])
+def test_phased_forward_is_bit_identical(shape):
+    """ncx_forward_phase PRELUDE (the data-only part: row ids, distance, rank one-hot, softmax statistics) then REST (everything
+    that reads the weights) == ncx_forward, bit for bit: scores AND every gradient of the backward that follows -- and the
+    prelude really reads no weight: it runs BEFORE the weights are replaced (what the pipelined data-parallel step does: the
+    next step's prelude is enqueued while the last Adam slice of the current one is still pending)."""
+    from neuralcx import ops
+    from neuralcx._lib import NCX_F_ALL, NCX_F_BF16
+    if shape == "configs1":
+        d, B = orc.Dims(), 512
+    elif shape == "bf16":
+        d, B = orc.Dims(dv=96, dq=64, dz=24, A=40, H=128, L=2), 9
+    else:
+        d, B = orc.Dims(dv=96, dq=64, dz=24, A=40, H=64, L=2), 31
+    flags = NCX_F_ALL | (NCX_F_BF16 if shape == "bf16" else 0)
+    params = orc.init_params(d, seed=9, gain=3.0)
+    batch = random_case(33, B, d)
+    b = to_dev_batch(batch)
+    p = to_dev_params(params)
+    gt = batch["gt"].to(dev()).to(torch.int32)
+    dims = ops.make_dims(b, H=d.H, L=d.L, da=d.da, A=d.A, flags=flags, training=True, drop_p=0.25, seed=77)
+    ws = ops.alloc_workspace(dims, dev())
+    s0 = ops.forward(dims, b, p, ws)
+    lr0 = ops.ranking_loss(s0, gt)
+    g0 = {k: torch.full_like(v, float("nan")) for k, v in p.items()}
+    ops.backward(dims, b, p, ws, lr0["dscores"], g0)
+    # a fresh workspace (nothing left over from the whole call), weights poisoned during the prelude
+    ws2 = ops.alloc_workspace(dims, dev()); ws2.zero_()
+    poisoned = {k: torch.full_like(v, float("nan")) for k, v in p.items()}
+    assert ops.forward(dims, b, poisoned, ws2, phase=ops.FWD_PRELUDE) is None
+    s1 = ops.forward(dims, b, p, ws2, phase=ops.FWD_REST)
+    assert torch.equal(s0, s1)
+    lr1 = ops.ranking_loss(s1, gt)
+    g1 = {k: torch.full_like(v, float("nan")) for k, v in p.items()}
+    ops.backward(dims, b, p, ws2, lr1["dscores"], g1)
+    for k in g0:
+        assert torch.isfinite(g1[k]).all() and torch.equal(g0[k], g1[k]), k
+
+
 def test_phased_backward_is_bit_identical():
     """ncx_backward_phase 1 then 2, and 3 then 4, == ncx_backward (what the data-parallel engine relies on)."""
     from neuralcx import ops

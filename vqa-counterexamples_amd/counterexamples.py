@@ -224,6 +224,7 @@ class Runner:
                 acc.zero_()
             if self.args.eval_freq > 0 and (bi + 1) % self.args.eval_freq == 0:
                 self.report("val", epoch, self.evaluate(self.val))
+        eng.flush()                                  # (data parallelism: the last step's deferred gradient bucket + Adam slice)
         torch.cuda.synchronize()
         return seen / (time.time() - t0)
 

@@ -69,7 +69,7 @@ static inline int wpad_width(const ncx_dims& d, int i) {
     if (d.flags & NCX_F_BF16) return 0;
     return (c == 0 || c % 32 == 0) ? 0 : pad_to(c, 32);
 }
-struct PackArgs { const float* src[WPAD_N + 1]; float* dst[WPAD_N + 1]; long long lds[WPAD_N + 1]; int cols[WPAD_N + 1], ldd[WPAD_N + 1], zero_from[WPAD_N + 1]; int n, H; };
+struct PackArgs { const float* src[WPAD_N + 1]; float* dst[WPAD_N + 1]; long long lds[WPAD_N + 1]; int cols[WPAD_N + 1], ldd[WPAD_N + 1], zero_from[WPAD_N + 1]; int n, H; int nprep; };   // nprep: row blocks (4 candidate rows each) in front of the pack blocks
 // dst[e][h][0 .. cols) = src[e][h][0 .. cols);  dst[e][h][zero_from .. ldd) = 0.   One block per (h, e): H * n blocks, which
 // ride at the end of k_prep's grid (a launch of their own cost 5 us for 0.5 MB of copies).
 __device__ __forceinline__ void pack_rows_block(const PackArgs& a, int idx) {
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_prep(ncx_dims d, ncx_inputs in, int* __
     constexpr int NR = RESIDENT ? 8 : 1;
     const int lane = threadIdx.x & 63;
     const int M = d.B * d.K;
-    const int nprep = (M + 3) / 4;
+    const int nprep = pk.nprep;                // (M + 3) / 4, or 0 in a pack-only launch (ncx_forward_phase: the weights-only half)
     if ((int)blockIdx.x >= nprep) { pack_rows_block(pk, (int)blockIdx.x - nprep); return; }     // the weight-pack blocks
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= M) return;
@@ -1131,7 +1131,7 @@ using namespace ncx;
 // =================================================================================================
 extern "C" {
 
-const char* ncx_version(void) { return "neuralcx-hip gfx950 fp32-mfma r3 (" __DATE__ ")"; }
+const char* ncx_version(void) { return "neuralcx-hip gfx950 fp32-mfma r4 (" __DATE__ ")"; }
 
 int64_t ncx_input_size(const ncx_dims* d) { return d ? (int64_t)seg_offsets(*d).din : 0; }
 
@@ -1140,11 +1140,32 @@ size_t ncx_workspace_bytes(const ncx_dims* d) {
     return ws_layout(*d).total;
 }
 
+static int forward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, void* workspace,
+                        size_t workspace_bytes, float* scores, void* stream_, int phase);
+
 int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, void* workspace,
                 size_t workspace_bytes, float* scores, void* stream_) {
+    return forward_impl(dp, in, p, workspace, workspace_bytes, scores, stream_, 0);
+}
+
+int ncx_forward_phase(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, void* workspace,
+                      size_t workspace_bytes, float* scores, int32_t phase, void* stream_) {
+    if (phase < 0 || phase > 2) return NCX_E_FLAGS;
+    return forward_impl(dp, in, p, workspace, workspace_bytes, scores, stream_, phase);
+}
+
+// phase 0: everything.  phase 1 (NCX_FWD_PRELUDE): the part that is a function of the DATA only -- k_prep's row pass (table row
+// ids, pairwise distance, rank one-hot, softmax statistics of the answer logits; the bf16 variant's row pack) -- so a
+// data-parallel job can run it for step n + 1 while step n's last gradient bucket is still on the wire and its weights are
+// not final.  phase 2 (NCX_FWD_REST): everything that reads the weights (the padded weight copies, Gt, Sh, the Linear layers,
+// the scores).  1 then 2 == 0 bit for bit: the same kernels on the same operands, k_prep's launch cut between its row blocks
+// and its weight-pack blocks.
+static int forward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, void* workspace,
+                        size_t workspace_bytes, float* scores, void* stream_, int phase) {
     int rc = check_dims(dp);
     if (rc != NCX_OK) return rc;
-    if (!in || !p || !workspace || (!scores && !(dp->flags & NCX_F_FUSED_TAIL))) return NCX_E_NULL;
+    const bool do_pre = phase != 2, do_rest = phase != 1;
+    if (!in || !p || !workspace || (do_rest && !scores && !(dp->flags & NCX_F_FUSED_TAIL))) return NCX_E_NULL;
     const ncx_dims& d = *dp;
     const bool aemb = d.flags & NCX_F_A_EMB;
     if (!in->feats || !in->img_idx || !in->q_emb || !in->z_orig || !in->z_knns || !in->a_knns) return NCX_E_NULL;
@@ -1206,12 +1227,20 @@ int ncx_forward(const ncx_dims* dp, const ncx_inputs* in, const ncx_params* p, v
                               main_split(M, H, main_T) == 1 && !vfold && !(hook_env("NCX_NO_DIST_IN_MAIN"));
     ncx_dims dprep = d;
     if (dist_in_main) dprep.flags |= NCX_F_PRIV_DIST_IN_MAIN;
-    const unsigned prep_grid = (unsigned)(cdiv(M, 4) + (long long)H * pk.n);
-    if (d.dv <= 2048 && d.A <= 2048)
-        hipLaunchKernelGGL(k_prep<true>, dim3(prep_grid), dim3(256), 0, s, dprep, *in, idx_k, idx_o, idx_ob, mx, inv, misc, xc, bf16_cols(d), pk);
-    else
-        hipLaunchKernelGGL(k_prep<false>, dim3(prep_grid), dim3(256), 0, s, dprep, *in, idx_k, idx_o, idx_ob, mx, inv, misc, xc, bf16_cols(d), pk);
-    NCX_HIP_TRY(hipGetLastError());
+    if (!do_rest) pk.n = 0;                                   // prelude: no weight is read
+    pk.nprep = do_pre ? (int)cdiv(M, 4) : 0;                  // rest: the pack blocks alone
+    const unsigned prep_grid = (unsigned)(pk.nprep + (long long)H * pk.n);
+    if (prep_grid > 0) {
+        if (d.dv <= 2048 && d.A <= 2048)
+            hipLaunchKernelGGL(k_prep<true>, dim3(prep_grid), dim3(256), 0, s, dprep, *in, idx_k, idx_o, idx_ob, mx, inv, misc, xc, bf16_cols(d), pk);
+        else
+            hipLaunchKernelGGL(k_prep<false>, dim3(prep_grid), dim3(256), 0, s, dprep, *in, idx_k, idx_o, idx_ob, mx, inv, misc, xc, bf16_cols(d), pk);
+        NCX_HIP_TRY(hipGetLastError());
+    }
+    if (!do_rest) {
+        if (ss) { rc = side_join(ss, s); if (rc) return rc; }
+        return NCX_OK;
+    }
 
     // Gt and Sh are two back-to-back split GEMMs on 64 x 64 tiles: their fix-ups (6 us each, mostly launch and ramp) run as one
     FixupArgs fix_gt{}, fix_sh{};

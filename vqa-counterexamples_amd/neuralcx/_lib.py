@@ -16,7 +16,7 @@ NCX_F_REUSE_GT = 32   # evaluation: Gt in the workspace is still valid (same wei
 NCX_F_FUSED_TAIL = 64  # training: out layer + loss / Recall + head of the backward in one pass (ncx_train_tail)
 NCX_F_BF16 = 16       # BASELINE configs[4]: bf16 operands for the two dominant GEMMs (include/neuralcx.h)
 
-EXPORTS = ("ncx_input_size", "ncx_workspace_bytes", "ncx_forward", "ncx_loss_rank", "ncx_backward", "ncx_backward_phase",
+EXPORTS = ("ncx_input_size", "ncx_workspace_bytes", "ncx_forward", "ncx_forward_phase", "ncx_loss_rank", "ncx_backward", "ncx_backward_phase",
            "ncx_adam_step", "ncx_version", "ncx_profile_begin", "ncx_profile_end", "ncx_plan_query",
            "ncx_vqa_workspace_bytes", "ncx_vqa_forward", "ncx_knn_workspace_bytes", "ncx_knn", "ncx_ws_region", "ncx_wgmap_check",
            "ncx_comm_unique_id", "ncx_comm_create", "ncx_comm_destroy", "ncx_allreduce", "ncx_train_tail", "ncx_profile_stamps")
@@ -84,6 +84,9 @@ def lib():
     L.ncx_forward.restype = C.c_int
     L.ncx_forward.argtypes = [C.POINTER(NcxDims), C.POINTER(NcxInputs), C.POINTER(NcxParams), C.c_void_p,
                               C.c_size_t, C.c_void_p, C.c_void_p]
+    L.ncx_forward_phase.restype = C.c_int
+    L.ncx_forward_phase.argtypes = [C.POINTER(NcxDims), C.POINTER(NcxInputs), C.POINTER(NcxParams), C.c_void_p,
+                                    C.c_size_t, C.c_void_p, C.c_int32, C.c_void_p]
     L.ncx_loss_rank.restype = C.c_int
     L.ncx_loss_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -84,10 +84,19 @@ class NeuralCXEngine:
         # stalls for each bucket, i.e. the part of the all-reduce the backward did NOT hide
         self.comm_profile = False
         self.comm_events = []
+        # data parallelism: the last gradient bucket (linear_1.weight .. out.bias) has nothing of its own step left to hide behind
+        # except the embedding's dE GEMM + Adam slice.  With `pipeline` its wait and the Adam slice it feeds are DEFERRED: the
+        # next train_step first enqueues its data-only forward prelude (ncx_forward_phase PRELUDE: k_prep, a function of the batch
+        # alone), then waits, applies the slice and runs the rest of the forward.  Same kernels on the same operands in an order
+        # that respects every dependency: weights bit-identical to the unpipelined engine.  Anything that reads the weights from
+        # outside a train_step (eval, state_dict, checkpoints) goes through flush() first.
+        self.pipeline = True
+        self._pending = None                      # (work handle of bucket 2, Adam step number, timing events)
 
     # ---- parameters --------------------------------------------------------------------------------------
     def init_parameters(self, seed=42, emb=None):
         """torch default init distributions: Embedding N(0,1), Linear U(+-1/sqrt(fan_in)) (cx.py:240-257)."""
+        self.flush()
         g = torch.Generator(device="cpu").manual_seed(seed)
         for n, v in self.params.views.items():
             if n == "answer_embedding.weight":
@@ -100,20 +109,24 @@ class NeuralCXEngine:
         self._weights_version += 1
 
     def load_state(self, state: Dict[str, torch.Tensor]):
+        self.flush()
         for n, v in self.params.views.items():
             v.copy_(state[n].to(self.device))
         self._weights_version += 1
 
     def state_dict(self):
+        self.flush()
         return {n: v.detach().clone() for n, v in self.params.views.items()}
 
     def optimizer_state(self):
         """Adam moments + step counter (net-new: the reference checkpoints the model only, counterexamples.py:550-560, so
         its --resume restarts Adam; with this a resumed run continues bit for bit)."""
+        self.flush()
         return {"exp_avg": self.exp_avg.detach().cpu(), "exp_avg_sq": self.exp_avg_sq.detach().cpu(), "step": self.step_count,
                 "numel": self.params.numel}
 
     def load_optimizer_state(self, st):
+        self.flush()
         if st["numel"] != self.params.numel:
             raise ValueError("optimizer state of another model (%d vs %d parameters)" % (st["numel"], self.params.numel))
         self.exp_avg.copy_(st["exp_avg"].to(self.device)); self.exp_avg_sq.copy_(st["exp_avg_sq"].to(self.device))
@@ -130,7 +143,21 @@ class NeuralCXEngine:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return d
 
+    def flush(self):
+        """Complete a deferred tail of the last train_step (data parallelism with `pipeline`): wait for its last gradient bucket
+        and apply the Adam slice it feeds.  No-op otherwise.  Every rank calls it at the same points (it holds no collective)."""
+        if self._pending is None:
+            return
+        h2, step, ev = self._pending
+        self._pending = None
+        n_emb = self.params.offsets["linear_1.weight"]
+        if ev: ev[2].record()
+        h2.wait()
+        if ev: ev[3].record(); self.comm_events.append(ev)
+        ops.adam_step(self.params.flat[n_emb:], self.grads.flat[n_emb:], self.exp_avg[n_emb:], self.exp_avg_sq[n_emb:], step, lr=self.lr)
+
     def forward(self, batch: ops.Batch, training=False):
+        self.flush()
         d = self._dims(batch, training, 0.0)
         # evaluation passes: Gt = W1[:, a_other] . E^T only depends on the weights -- reuse it while neither the weights
         # (train_step / load_state / init_parameters bump _weights_version) nor the workspace changed
@@ -161,7 +188,13 @@ class NeuralCXEngine:
         fused = active and self.fused_tail and ops.fused_tail_ok(d)
         if fused:
             d.flags |= NCX_F_FUSED_TAIL
-        scores = ops.forward(d, batch, self.params.fields(), self._ws)
+        if self._pending is not None:
+            # the previous step's last bucket is still on the wire: this step's data-only prelude runs under it
+            ops.forward(d, batch, self.params.fields(), self._ws, phase=ops.FWD_PRELUDE)
+            self.flush()
+            scores = ops.forward(d, batch, self.params.fields(), self._ws, phase=ops.FWD_REST)
+        else:
+            scores = ops.forward(d, batch, self.params.fields(), self._ws)
         if fused:
             r = ops.train_tail(d, self.params.fields(), self._ws, scores, gt, self.grads.fields())
         else:
@@ -191,11 +224,9 @@ class NeuralCXEngine:
                 # answer_embedding's gradient is complete on every rank: its Adam slice also runs under bucket 2
                 ops.adam_step(self.params.flat[:n_emb], self.grads.flat[:n_emb], self.exp_avg[:n_emb], self.exp_avg_sq[:n_emb],
                               self.step_count, lr=self.lr)
-                if ev: ev[2].record()
-                h2.wait()
-                if ev: ev[3].record(); self.comm_events.append(ev)
-                ops.adam_step(self.params.flat[n_emb:], self.grads.flat[n_emb:], self.exp_avg[n_emb:], self.exp_avg_sq[n_emb:],
-                              self.step_count, lr=self.lr)
+                self._pending = (h2, self.step_count, ev)
+                if not self.pipeline:
+                    self.flush()                     # wait for bucket 2 + the tail Adam slice now
                 r["scores"] = scores
                 return r
             else:                                   # a_emb lesion: the embedding gradient is zero everywhere

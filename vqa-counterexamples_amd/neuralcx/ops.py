@@ -162,13 +162,25 @@ def train_tail(d: NcxDims, params: Dict[str, torch.Tensor], ws: torch.Tensor, sc
     return dict(loss=loss, loss_rows=loss_rows, dscores=dscores, rank=rank, hits=hits)
 
 
-def forward(d: NcxDims, batch: Batch, params: Dict[str, torch.Tensor], ws: torch.Tensor) -> torch.Tensor:
-    """-> scores [B, K] (with NCX_F_FUSED_TAIL in d.flags: allocated here, written by train_tail)."""
-    scores = torch.empty(d.B, d.K, dtype=torch.float32, device=batch.feats.device)
+FWD_ALL, FWD_PRELUDE, FWD_REST = 0, 1, 2
+
+
+def forward(d: NcxDims, batch: Batch, params: Dict[str, torch.Tensor], ws: torch.Tensor, phase: int = FWD_ALL) -> Optional[torch.Tensor]:
+    """-> scores [B, K] (with NCX_F_FUSED_TAIL in d.flags: allocated here, written by train_tail).
+    phase (ncx_forward_phase): FWD_PRELUDE = the data-only part (returns None), FWD_REST = everything that reads the weights;
+    PRELUDE then REST on the same workspace == the whole forward, bit for bit."""
     p, n = _ws_ptr(ws)
     ins, ps = batch.c_struct(), _params_struct(params, NcxParams)
-    _lib.check(_lib.lib().ncx_forward(C.byref(d), C.byref(ins), C.byref(ps), p, n,
-                                      C.c_void_p(scores.data_ptr()), _stream()), "ncx_forward")
+    if phase == FWD_PRELUDE:
+        _lib.check(_lib.lib().ncx_forward_phase(C.byref(d), C.byref(ins), C.byref(ps), p, n, None, FWD_PRELUDE, _stream()), "ncx_forward_phase")
+        return None
+    scores = torch.empty(d.B, d.K, dtype=torch.float32, device=batch.feats.device)
+    if phase == FWD_ALL:
+        _lib.check(_lib.lib().ncx_forward(C.byref(d), C.byref(ins), C.byref(ps), p, n,
+                                          C.c_void_p(scores.data_ptr()), _stream()), "ncx_forward")
+    else:
+        _lib.check(_lib.lib().ncx_forward_phase(C.byref(d), C.byref(ins), C.byref(ps), p, n,
+                                                C.c_void_p(scores.data_ptr()), int(phase), _stream()), "ncx_forward_phase")
     return scores
 
 
