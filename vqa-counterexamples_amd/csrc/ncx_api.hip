@@ -10,6 +10,7 @@
 //   h2, h3 (L >= 2), scores = h_L . w_out + b_out                                                     [MFMA/HBM]
 // Backward mirrors it (see ncx_backward).  Nothing here allocates or synchronises.
 #include "ncx_internal.h"
+#include "ncx_dwred.h"
 #include "ncx_bf16.h"
 #include <stdlib.h>
 #include <stdio.h>
@@ -872,8 +873,9 @@ static void list_uses(const ncx_dims& d, GemmUse* u) {
     for (int i = 0; i < U_COUNT; ++i) {
         // grouped launches (DW1C + DW1S): tiles are counted per column segment
         const bool km = dw_km_supported(d) && !(d.flags & NCX_F_BF16);     // v_other / v_mult columns: ncx_dwkm.hip
-        const long long segs_c[5] = {km ? 0 : d.dv, (!km && (d.flags & NCX_F_V_MULT)) ? d.dv : 0, d.K + 1, d.dz, aemb ? d.A : d.da};
-        const long long segs_s[5] = {d.dv, d.dq, d.dz, d.da, 0};
+        const bool tn8 = dw_tn8_supported(d);                               // every other column block + dGt: ncx_dwtn.hip
+        const long long segs_c[5] = {km ? 0 : d.dv, (!km && (d.flags & NCX_F_V_MULT)) ? d.dv : 0, tn8 ? 0 : d.K + 1, tn8 ? 0 : d.dz, tn8 ? 0 : (aemb ? d.A : d.da)};
+        const long long segs_s[5] = {tn8 ? 0 : d.dv, tn8 ? 0 : d.dq, tn8 ? 0 : d.dz, tn8 ? 0 : d.da, 0};
         const bool grouped = i == U_DW1C || i == U_DW1S;
         auto grouped_tiles = [&](int bm, int bn) {
             const long long* sg = i == U_DW1C ? segs_c : segs_s;
@@ -881,7 +883,9 @@ static void list_uses(const ncx_dims& d, GemmUse* u) {
             for (int q = 0; q < 5; ++q) t += cdiv(H, bm) * cdiv(sg[q], bn);
             return t;
         };
-        if (grouped) {
+        if (grouped && grouped_tiles(64, 64) == 0) {      // nothing left for the grouped launch
+            u[i].plan.cfg = CFG_128x64; u[i].plan.split = 1;
+        } else if (grouped) {
             u[i].plan = plan_from_tiles(FORM_TN, grouped_tiles(128, 128), grouped_tiles(64, 64), u[i].ksteps, false);
             // Measured on MI355X (C2, H=256: 206 tiles of 128x64 x 384 k-steps): 128x64 with 6-8 k-chunks 0.448 ms vs
             // 0.476 ms for 64x64 x 8; three rounds of the 2-per-CU slots.
@@ -927,10 +931,12 @@ static void list_uses(const ncx_dims& d, GemmUse* u) {
     u[U_DW1S].plan.cfg = u[U_DW1C].plan.cfg;
     {
         int bm, bn; cfg_tile(u[U_DW1C].plan.cfg, bm, bn);
-        const long long segs_s[4] = {d.dv, d.dq, d.dz, d.da};
+        const bool tn8 = dw_tn8_supported(d);
+        const long long segs_s[4] = {tn8 ? 0 : d.dv, tn8 ? 0 : d.dq, tn8 ? 0 : d.dz, tn8 ? 0 : d.da};
         const int S = u[U_DW1S].plan.split > 1 ? u[U_DW1S].plan.split : 1;
         u[U_DW1S].tiles = 0; u[U_DW1S].wgs = 0;
         for (int q = 0; q < 4; ++q) {
+            if (segs_s[q] == 0) continue;
             u[U_DW1S].tiles += cdiv(H, bm) * cdiv(segs_s[q], bn);
             u[U_DW1S].wgs += WgMap{(int)cdiv(H, bm), (int)cdiv(segs_s[q], bn), S}.count();
         }
@@ -965,6 +971,7 @@ WsLayout ws_layout(const ncx_dims& d) {
     long long slab = 0;
     for (int i = 0; i < U_COUNT; ++i) slab = u[i].slab_elems > slab ? u[i].slab_elems : slab;
     w.slab_bytes = (size_t)slab * 4;
+    if (dw_tn8_slab_bytes(d) > w.slab_bytes) w.slab_bytes = dw_tn8_slab_bytes(d);      // ncx_dwtn.hip: its partial tiles live here too
     w.slab = take(w.slab_bytes);
     {   // side-stream GEMMs (Gt, Sh forward; dW1ak, dE backward) get their own slab
         long long s2 = u[U_GT].slab_elems;
@@ -1559,7 +1566,7 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
         NCX_HIP_TRY(hipGetLastError());
         rc = colsum(dsh, nullptr, d.B, H, g->b1); if (rc) return rc;
     }
-    bool km_deferred = false;
+    bool km_deferred = false, km_reduced = false;
     auto run_km = [&](bool finish = true) -> int {
         int r = prof_open(U_DW1C, s); if (r) return r;
         r = dw_km(d, dpre, in->feats, idx_k, idx_o, (float*)(ws + w.km_slab), g->w1 + o.v_other, g->w1 + o.v_mult, din, s, finish);
@@ -1586,6 +1593,7 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
             rc = prof_close(U_DW1C, s); if (rc) return rc;
         }
         const bool km = dw_km_supported(d) && !bf16;
+        const bool tn8 = dw_tn8_supported(d);               // dGt + every column block that is not the per-triplet fold's: ONE balanced launch (ncx_dwtn.hip)
         // With the side stream the per-triplet fold kernel (a full round of long workgroups) is launched AFTER the grouped
         // launch, next to the answer-embedding chain (dW1ak, dE: short latency-bound workgroups) that waits for dGt.
         km_deferred = want_rest && km && aemb && do1 && do2 && side_stream() != nullptr && side_stream()->mode != 2;
@@ -1598,15 +1606,41 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
             add_c(x_gather(in->feats, d.dv, idx_k, M, d.dv), g->w1 + o.v_other, din);
             if (d.flags & NCX_F_V_MULT) add_c(x_gather_mul(in->feats, d.dv, idx_k, idx_o, M, d.dv), g->w1 + o.v_mult, din);
         }
-        if (want_rest && !bf16) {
+        if (tn8 && (want_dgt || want_rest)) {
+            // The problem list is the same in every phase (the chunking of the dGt part and of the rest do not depend on each other,
+            // and the slab slots are numbered over the whole list): phases 5 | 2 launch its two parts separately, bit-identically.
+            Tn8Prob tp[TN8_MAX_PROB]; int np = 0, n_al = 0;
+            auto prob = [&](const float* A_, int rows, const float* X, long long ldx, const float* lse, int gsel, int N, float* out, long long ldo, int n_valid) {
+                Tn8Prob& q = tp[np++]; q.A = A_; q.rows = rows; q.X = X; q.ldx = ldx; q.lse = lse; q.gsel = gsel; q.N = N; q.out = out; q.ldo = ldo; q.n_valid = n_valid; };
+            if (aemb) { prob(dpre, M, in->a_knns, d.A, mx, 0, d.A, dgt, d.A, d.A); n_al = 1; }
+            else prob(dpre, M, in->a_knns, d.da, nullptr, 0, d.da, g->w1 + o.a_other, din, d.da);
+            prob(dpre, M, in->z_knns, d.dz, nullptr, 0, d.dz, g->w1 + o.z_other, din, d.dz);
+            prob(dpre, M, misc, w.ldm, nullptr, 0, w.ldm, g->w1 + o.v_dist, din, d.K + 1);
+            prob(dsh, d.B, in->feats, d.dv, nullptr, 1, d.dv, g->w1 + o.v_orig, din, d.dv);
+            prob(dsh, d.B, in->q_emb, d.dq, nullptr, 0, d.dq, g->w1 + o.q_emb, din, d.dq);
+            prob(dsh, d.B, in->z_orig, d.dz, nullptr, 0, d.dz, g->w1 + o.z_orig, din, d.dz);
+            if (aemb) prob(dsh, d.B, p->answer_embedding, d.da, nullptr, 2, d.da, g->w1 + o.a_gt, din, d.da);
+            else      prob(dsh, d.B, in->a_emb_gt, d.da, nullptr, 0, d.da, g->w1 + o.a_gt, din, d.da);
+            // ... and ONE launch sums its partial tiles and the fold kernel's k-chunks (when that kernel ran just above)
+            const bool with_km = want_rest && km && !km_deferred && km_merge;
+            Tn8ReduceArgs red{};
+            rc = prof_open(U_DW1C, s); if (rc) return rc;
+            rc = dw_tn8_products(d, tp, np, n_al, want_dgt, want_rest, idx_ob, aemb ? in->answer_aids : nullptr, slab, w.slab_bytes, &red, s); if (rc) return rc;
+            bool kvec = true;
+            KmReduceArgs kr{};
+            if (with_km) { kr = dw_km_reduce_args(d, (const float*)(ws + w.km_slab), g->w1 + o.v_other, g->w1 + o.v_mult, din, &kvec); km_reduced = true; }
+            rc = dw_reduce_km_tn8(with_km ? &kr : nullptr, kvec, &red, s); if (rc) return rc;
+            rc = prof_close(U_DW1C, s); if (rc) return rc;
+        }
+        if (want_rest && !bf16 && !tn8) {
             if (!aemb) add_c(x_plain(in->a_knns, d.da, M, d.da), g->w1 + o.a_other, din);
         }
-        if (want_dgt) add_c(x_softmax(in->a_knns, d.A, mx, inv, M, d.A), dgt, d.A);
-        if (want_rest && !bf16) {      // the narrow problems last among the candidate ones (shorter k-chunks: see dw1c_seg_split)
+        if (want_dgt && !tn8) add_c(x_softmax(in->a_knns, d.A, mx, inv, M, d.A), dgt, d.A);
+        if (want_rest && !bf16 && !tn8) {      // the narrow problems last among the candidate ones (shorter k-chunks: see dw1c_seg_split)
             add_c(x_plain(in->z_knns, d.dz, M, d.dz), g->w1 + o.z_other, din);
             add_c(x_plain(misc, w.ldm, M, d.K + 1), g->w1 + o.v_dist, din);
         }
-        if (want_rest) {
+        if (want_rest && !tn8) {
             add_s(x_gather(in->feats, d.dv, idx_ob, d.B, d.dv), g->w1 + o.v_orig);
             add_s(x_plain(in->q_emb, d.dq, d.B, d.dq), g->w1 + o.q_emb);
             add_s(x_plain(in->z_orig, d.dz, d.B, d.dz), g->w1 + o.z_orig);
@@ -1617,7 +1651,7 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
         FixupArgs fix_tn{};
         if (km_merge) a.defer_fix = &fix_tn;
         if (n > 0) { rc = run_gemm(U_DW1C, a, FORM_TN, u[U_DW1C].plan, slab, w.slab_bytes, nullptr, s); if (rc) return rc; }
-        if (km_merge) {
+        if (km_merge && !km_reduced) {
             rc = prof_open(U_DW1C, s); if (rc) return rc;
             rc = dw_km_finish(d, (const float*)(ws + w.km_slab), g->w1 + o.v_other, g->w1 + o.v_mult, din, &fix_tn, u[U_DW1C].plan.cfg, s);
             if (rc) return rc;

@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "ncx_internal.h"
+#include "ncx_dwred.h"
 
 namespace ncx {
 
@@ -241,32 +242,6 @@ __global__ __launch_bounds__(T, OCC) void k_dw_km(const float* __restrict__ dpre
         }
 }
 
-// Fixed-order sum of the k-chunk partials.  VEC: 4 consecutive columns per thread (dv % 4 == 0); all chunk loads are issued
-// before the first add (DW_KM_SPLIT is a compile-time bound: a runtime-length loop made every chunk a dependent round trip).
-struct KmReduceArgs { const float* slab; int nz, H, dv; long long din; float* g_vother; float* g_vmult; int nblk; };
-template <bool VEC>
-__device__ __forceinline__ void km_reduce_body(const KmReduceArgs& r, int blk) {
-    constexpr int W = VEC ? 4 : 1;
-    typedef float vec __attribute__((ext_vector_type(VEC ? 4 : 1)));
-    const long long i = ((long long)blk * 256 + threadIdx.x) * W, n = (long long)r.H * r.dv;
-    if (i >= n) return;
-    const int h = (int)(i / r.dv), c = (int)(i - (long long)h * r.dv);
-    vec vk[DW_KM_SPLIT], vm[DW_KM_SPLIT];
-#pragma unroll
-    for (int z = 0; z < DW_KM_SPLIT; ++z) {
-        const int zz = z < r.nz ? z : r.nz - 1;
-        vk[z] = *(const vec*)(r.slab + ((long long)zz * 2 + 0) * n + i);
-        vm[z] = *(const vec*)(r.slab + ((long long)zz * 2 + 1) * n + i);
-    }
-    vec sk = vk[0], sm = vm[0];
-#pragma unroll
-    for (int z = 1; z < DW_KM_SPLIT; ++z) { const vec zero = {}; sk += z < r.nz ? vk[z] : zero; sm += z < r.nz ? vm[z] : zero; }
-#pragma unroll
-    for (int j = 0; j < W; ++j) {                        // (rows of linear_1.weight are din floats apart: not 16-byte aligned in general)
-        r.g_vother[(long long)h * r.din + c + j] = sk[j];
-        r.g_vmult[(long long)h * r.din + c + j] = sm[j];
-    }
-}
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_dw_km_reduce(const KmReduceArgs r) { km_reduce_body<VEC>(r, blockIdx.x); }
 // ... and, in the same launch, the split fix-up of the grouped GEMM that computes the other columns of linear_1's gradient
@@ -293,6 +268,16 @@ static int km_chunks(const ncx_dims& d, int& chunk) {
     const int S = d.B / 16 >= DW_KM_SPLIT ? DW_KM_SPLIT : (d.B / 16 >= 1 ? d.B / 16 : 1);
     chunk = (d.B + S - 1) / S;
     return S;
+}
+
+KmReduceArgs dw_km_reduce_args(const ncx_dims& d, const float* slab, float* g_vother, float* g_vmult, long long din, bool* vec) {
+    int chunk; km_chunks(d, chunk);
+    KmReduceArgs r{};
+    r.slab = slab; r.nz = (d.B + chunk - 1) / chunk; r.H = d.H; r.dv = d.dv; r.din = din; r.g_vother = g_vother; r.g_vmult = g_vmult;
+    const long long n = (long long)d.H * d.dv;
+    *vec = d.dv % 4 == 0 && ((uintptr_t)slab & 15) == 0;
+    r.nblk = (int)(((*vec ? n / 4 : n) + 255) / 256);
+    return r;
 }
 
 // The fixed-order sum of the k-chunk partials; `fix` (may be null / invalid): a deferred split fix-up of tile shape `fix_cfg` that

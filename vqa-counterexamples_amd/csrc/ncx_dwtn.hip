@@ -1,0 +1,391 @@
+// ncx_dwtn.hip -- the row-reduction (TN) weight-gradient products of linear_1 that are NOT the per-triplet fold (ncx_dwkm.hip), as ONE
+// balanced launch of 8-wave workgroups (round 4):
+//
+//   dGt[h][a]             = sum_r dpre[r][h] * softmax(a_knns)[r][a]          (M = B K rows; what the answer_embedding gradient waits for)
+//   dW1[:, z_other][h][c]  = sum_r dpre[r][h] * z_knns[r][c]
+//   dW1[:, dist|rank][h][c] = sum_r dpre[r][h] * misc[r][c]
+//   dW1[:, shared][h][c]   = sum_b dSh[b][h] * [v_o | q | z_o | E[aid]][b][c]   (B rows)
+//
+// Reference: the gradients autograd produces for vqa/models/cx.py:309-322 (same products the generic engine's grouped launch computed).
+//
+// Why a kernel of its own.  On the generic engine (128 x 64 tiles, 4 waves, two workgroups per CU) the dGt problem alone ran at 0.64 of
+// the fp32-MFMA peak and the short problems behind it added 61 us for 4.3 GF (tools/exp_dw1c_split.py): 175 us for the launch.  Here
+//   * a workgroup is 8 waves on a 256 x 64 tile = ALL of H (one workgroup per CU): every operand row is fetched, transformed (softmax)
+//     and stored to LDS once per 256 output rows instead of once per 128; 64 MFMAs per wave between two barriers; two register sets of
+//     global loads in flight (a load has 1.5 k-steps to land), the LDS stores of the next tile and the loads of the one after spread
+//     under the MFMAs of the current one, the last sub-step's MFMAs issued after the barrier (tools/mb/mb_tn.hip: dGt alone
+//     125 -> 109 us; LDS-DMA staging measured there too: slower, 121 us);
+//   * the launch is BALANCED: workgroup w owns one aligned chunk of a dGt tile (S row chunks per tile, tiles x S = the grid) and then the
+//     range [w R, (w + 1) R) of the k-steps of all other tiles laid end to end (unaligned: a range may cover the tail of one tile and
+//     the head of the next; every piece goes to its own slab slot, the reduction that follows sums a tile's pieces in ascending
+//     workgroup order: deterministic).  The operand loader follows the workgroup's step sequence across piece boundaries (its
+//     descriptors come from a table in LDS, one step ahead), so a switch costs an accumulator flush, not a pipeline restart.
+//   * The chunking of the dGt part does not depend on whether the rest is launched with it, and vice versa: the phased backward
+//     (ncx_backward_phase 5 | 2 | 4) is bit-identical to the whole one.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <type_traits>
+#include "ncx_internal.h"
+#include "ncx_dwred.h"
+
+namespace ncx {
+
+constexpr int TN8_PA = 256, TN8_PB = 80;                       // LDS pitches (floats): ds_read_b128 / ds_read_b64 fragment reads without conflicts
+constexpr int TN8_MAX_SEG = 16;                                // pieces per workgroup (host-checked)
+constexpr int TN8_SEG_WORDS = 16;
+
+typedef const __attribute__((address_space(1))) float* tn_gfptr;
+typedef const __attribute__((address_space(1))) f32x4u* tn_gf4ptr;
+
+struct Tn8Args {
+    Tn8Prob p[TN8_MAX_PROB];
+    int np, n_al;                     // problems [0, n_al) are "aligned" (n_al <= 1), [n_al, np) make up the rest sequence
+    int H, tiles_m, B;
+    int S, al_wgs, al_tiles_n;        // aligned problem: S row chunks per tile, al_wgs = tiles x S workgroups
+    int R;                            // rest k-steps per workgroup
+    int do_al, do_rest;
+    int rest_tiles[TN8_MAX_PROB], rest_steps[TN8_MAX_PROB], rest_tile0[TN8_MAX_PROB];   // per problem: tiles (row tiles x column tiles), k-steps per tile, first global rest tile
+    int rest_pre[TN8_MAX_PROB + 1];   // prefix sums of tiles x steps over the rest problems (rest_pre[np] = all rest k-steps)
+    const int* idx_ob; const int* aid;
+    float* slab;                      // [slot][256][64]
+    int n_slots;
+};
+
+// LDS image of one piece of a workgroup's step sequence (16 dwords)
+struct Tn8Seg {
+    unsigned long long a_ptr;         // A + row-tile offset (floats are added per step)
+    unsigned long long x_ptr;         // X
+    unsigned long long l_ptr;         // lse (or any readable address when soft == 0)
+    int ldx;                          // floats
+    int soft;                         // 1: x = exp2(X log2e - lse[r])
+    int gsel;                         // 0: row r; 1 / 2: row idx table 0 / 1 in LDS
+    int n0, ncl;                      // first column of the tile; N - 4 (the 16-byte windows are clamped into the row)
+    int t0;                           // first k-step of the piece
+    int vbeg, vend;                   // the piece's range in the workgroup's virtual step sequence
+    int slot;                         // slab slot of the partial tile
+    int pad;
+};
+static_assert(sizeof(Tn8Seg) == TN8_SEG_WORDS * 4, "segment record");
+
+__global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
+    constexpr int T = TN8_T, BM = TN8_BM, BN = TN8_BN, BK = TN8_BK, PA = TN8_PA, PB = TN8_PB;
+    constexpr int WM = 4, WN = 2, NA = 4, NMF = 2 * WM * WN;
+    extern __shared__ __attribute__((aligned(16))) float tn_smem[];
+    float* const lds_a = tn_smem;                               // [2][32][PA]
+    float* const lds_b = tn_smem + 2 * BK * PA;                 // [2][32][PB]
+    Tn8Seg* const segs = (Tn8Seg*)(tn_smem + 2 * BK * (PA + PB));          // [TN8_MAX_SEG]
+    int* const lds_idx = (int*)(segs + TN8_MAX_SEG);            // [2][B]: idx_ob, answer ids (row gathers of the per-triplet problems)
+    __shared__ int s_nseg, s_vtot;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int wm0 = 64 * (wave >> 1), wn0 = 32 * (wave & 1);
+    const int w = blockIdx.x;
+
+    // ---- this workgroup's pieces ---------------------------------------------------------------------------------------------------
+    if (tid == 0) {
+        int n = 0, v = 0;
+        auto put = [&](int prob, int tile, int t0, int t1, int slot) {
+            const Tn8Prob& p = a.p[prob];
+            const int tm = tile % a.tiles_m, tn = tile / a.tiles_m;
+            Tn8Seg sg;
+            sg.a_ptr = (unsigned long long)(uintptr_t)(p.A + (long long)tm * BM);
+            sg.x_ptr = (unsigned long long)(uintptr_t)p.X;
+            sg.l_ptr = (unsigned long long)(uintptr_t)(p.lse ? p.lse : p.A);
+            sg.ldx = (int)p.ldx; sg.soft = p.lse ? 1 : 0; sg.gsel = p.gsel;
+            sg.n0 = tn * BN; sg.ncl = p.N - 4; sg.t0 = t0; sg.vbeg = v; sg.vend = v + (t1 - t0); sg.slot = slot; sg.pad = 0;
+            if (n < TN8_MAX_SEG) segs[n++] = sg;
+            v += t1 - t0;
+        };
+        if (a.do_al && w < a.al_wgs) {
+            const int tile = w / a.S, z = w - tile * a.S;
+            const int steps = a.p[0].rows / BK;
+            const int g0 = (int)((long long)steps * z / a.S), g1 = (int)((long long)steps * (z + 1) / a.S);
+            if (g1 > g0) put(0, tile, g0, g1, w);
+        }
+        if (a.do_rest) {
+            long long g = (long long)w * a.R;
+            const long long gend = min(g + a.R, (long long)a.rest_pre[a.np]);
+            int pr = a.n_al;
+            while (g < gend) {
+                while (pr + 1 < a.np && g >= a.rest_pre[pr + 1]) ++pr;
+                const int local = (int)(g - a.rest_pre[pr]);
+                const int tile = local / a.rest_steps[pr], t0 = local - tile * a.rest_steps[pr];
+                const int t1 = (int)min((long long)a.rest_steps[pr], t0 + (gend - g));
+                put(pr, tile, t0, t1, a.al_wgs + a.rest_tile0[pr] + tile + w);
+                g += t1 - t0;
+            }
+        }
+        s_nseg = n; s_vtot = v;
+    }
+    if (a.do_rest) {                                            // row-gather tables of the per-triplet problems
+        for (int i = tid; i < a.B; i += T) { lds_idx[i] = a.idx_ob ? a.idx_ob[i] : 0; lds_idx[a.B + i] = a.aid ? a.aid[i] : 0; }
+    }
+    __syncthreads();
+    const int nseg = s_nseg, V = s_vtot;
+    if (V == 0) return;
+
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- loader: follows the virtual step sequence; its piece record travels one issue ahead -------------------------------------------
+    const int arow = tid >> 6, aq = tid & 63;                   // A item i: tile row arow + 8 i, 16-byte quad aq
+    const int brow = tid >> 4, bq = tid & 15;                   // X item: tile row brow, quad bq
+    f32x4 va[2][NA], vb[2];
+    float vl[2], vs[2];                                         // lse of the X item's row; 1 = softmax piece
+    int qi = 0;                                                 // piece of the NEXT issue
+    Tn8Seg dn = segs[0];
+    // ... and so does the gathered row of the X item (an index read inside issue() would put an LDS round trip in front of its load)
+    auto gather_row = [&](const Tn8Seg& sg, int v) __attribute__((always_inline)) -> int {
+        const int r = (sg.t0 + (min(v, V - 1) - sg.vbeg)) * BK + brow;
+        return lds_idx[(sg.gsel == 2 ? a.B : 0) + (sg.gsel ? min(r, a.B - 1) : 0)];
+    };
+    int rgn = gather_row(dn, 0);
+    auto issue = [&](auto set_c, int v) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_c)::value;
+        // (virtual steps beyond the sequence re-load the last tile; never consumed)
+        const int vv = min(v, V - 1);
+        const int t = dn.t0 + (vv - dn.vbeg);
+        const long long r0 = (long long)t * BK;
+        const tn_gfptr ap = (tn_gfptr)(uintptr_t)dn.a_ptr + (r0 + arow) * a.H + 4 * aq;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) va[S][i] = *(tn_gf4ptr)(ap + (long long)(8 * i) * a.H);
+        const int r = (int)r0 + brow;
+        const long long xr = dn.gsel ? (long long)rgn : (long long)r;
+        vb[S] = *(tn_gf4ptr)((tn_gfptr)(uintptr_t)dn.x_ptr + xr * dn.ldx + min(dn.n0 + 4 * bq, dn.ncl));
+        vl[S] = ((tn_gfptr)(uintptr_t)dn.l_ptr)[dn.soft ? r : 0];
+        vs[S] = dn.soft ? 1.f : 0.f;
+        // the record of the next issue (read now, used one k-step from now)
+        qi += (v + 1 >= dn.vend && qi + 1 < nseg) ? 1 : 0;
+        dn = segs[qi];
+        rgn = gather_row(dn, v + 1);
+    };
+    auto stash = [&](auto set_c, int buf, int h0, int h1) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_c)::value;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (i < h0 || i >= h1) continue;
+            *(f32x4*)(lds_a + buf * BK * PA + (arow + 8 * i) * PA + 4 * aq) = va[S][i];
+        }
+        if (NA >= h0 && NA < h1) {
+            f32x4 v = vb[S], e;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[j], 1.44269504088896341f, -vl[S]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = vs[S] != 0.f ? e[j] : v[j];
+            *(f32x4*)(lds_b + buf * BK * PB + brow * PB + 4 * bq) = v;
+        }
+    };
+    f32x4 afA[2], afB[2];                 // [e]: the 4 interleaved A blocks of a 16-byte read
+    f32x2 bfA[2], bfB[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) { afB[e] = f32x4{0.f, 0.f, 0.f, 0.f}; bfB[e] = f32x2{0.f, 0.f}; }
+    // Interleaved block mapping: MFMA block q of a wave owns tile rows {wm0 + 4 i + q} (columns {wn0 + 2 j + q}), so one ds_read_b128
+    // (ds_read_b64) per k-row feeds all four (two) blocks.  k order inside a step: MFMA (s, e) takes k = 8 s + 2 lk + e from lane group lk.
+    auto read_frags = [&](int buf, int s, f32x4 (&af)[2], f32x2 (&bf)[2]) __attribute__((always_inline)) {
+        const int kk = 8 * s + 2 * lk;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            af[e] = *(const f32x4*)(lds_a + buf * BK * PA + (kk + e) * PA + wm0 + 4 * li);
+            bf[e] = *(const f32x2*)(lds_b + buf * BK * PB + (kk + e) * PB + wn0 + 2 * li);
+        }
+    };
+    auto mfma = [&](const f32x4 (&af)[2], const f32x2 (&bf)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e][i], bf[e][j], acc[i][j], 0, 0, 0);
+    };
+    typedef std::integral_constant<int, 0> S0; typedef std::integral_constant<int, 1> S1;
+    issue(S0{}, 0);
+    issue(S1{}, 1);
+    stash(S0{}, 0, 0, NA + 1);
+    issue(S0{}, 2);
+    __syncthreads();
+    // the piece being multiplied
+    int qc = 0, vend_c = segs[0].vend, slot_c = segs[0].slot;
+    auto flush = [&]() __attribute__((always_inline)) {          // partial tile -> its slab slot; lane holds, per (block q, reg), 2 consecutive columns
+        float* const slot = a.slab + (long long)slot_c * (BM * BN);
+#pragma unroll
+        for (int q = 0; q < WM; ++q)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int row = wm0 + 4 * (4 * lk + rg) + q;
+                const f32x2 v = {acc[q][0][rg], acc[q][1][rg]};
+                *(f32x2*)(slot + row * BN + wn0 + 2 * li) = v;
+                acc[q][0][rg] = 0.f; acc[q][1][rg] = 0.f;
+            }
+    };
+    auto step = [&](auto par_c, int v) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_c)::value;
+        typedef std::integral_constant<int, PAR ^ 1> SS;
+        read_frags(PAR, 0, afA, bfA);
+        mfma(afB, bfB);                                  // (v - 1, last sub-step; zeros after a flush): covers the reads above
+#pragma unroll
+        for (int q = 0; q < NMF; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            auto& afc = (s & 1) ? afB : afA; auto& bfc = (s & 1) ? bfB : bfA;
+            auto& afn = (s & 1) ? afA : afB; auto& bfn = (s & 1) ? bfA : bfB;
+            read_frags(PAR, s + 1, afn, bfn);
+            if (s == 0) stash(SS{}, PAR ^ 1, 0, 2);
+            if (s == 1) stash(SS{}, PAR ^ 1, 2, NA + 1);
+            if (s == 2) issue(SS{}, v + 3);
+            mfma(afc, bfc);
+#pragma unroll
+            for (int q = 0; q < NMF; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        if (v + 1 == vend_c) {                           // the piece ends here (uniform): last sub-step, partial tile out, next piece
+            mfma(afB, bfB);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) { afB[e] = f32x4{0.f, 0.f, 0.f, 0.f}; bfB[e] = f32x2{0.f, 0.f}; }
+            flush();
+            ++qc;
+            if (qc < nseg) { vend_c = segs[qc].vend; slot_c = segs[qc].slot; }
+        }
+    };
+    int v = 0;
+    for (; v + 1 < V; v += 2) { step(S0{}, v); step(S1{}, v + 1); }
+    if (v < V) step(S0{}, v);
+}
+
+
+// ---- host ------------------------------------------------------------------------------------------------------------------------------
+static inline int tn8_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+bool dw_tn8_supported(const ncx_dims& d) {
+    if (hook_env("NCX_NO_TN8")) return false;
+    if (d.flags & NCX_F_BF16) return false;
+    const long long M = (long long)d.B * d.K;
+    // all of H in 256-row tiles; whole 32-row k-steps for both reduction extents; 16-byte operand windows; the per-triplet row-gather
+    // tables fit in LDS; enough k-steps per chunk to be worth a pipeline (below that the generic engine's plans are as good)
+    if (d.H % TN8_BM != 0 || d.B % TN8_BK != 0 || M % TN8_BK != 0 || d.B > 4096 || d.B < 128) return false;
+    if (d.dv % 4 || d.dq % 4 || d.dz % 4 || d.da % 4 || d.A % 4) return false;
+    return true;
+}
+
+struct Tn8Plan { int grid, S, al_wgs, al_tiles, R, n_slots, rest_tiles_total; };
+static Tn8Plan tn8_plan(const ncx_dims& d, const Tn8Prob* p, int np, int n_al, int* rest_tiles, int* rest_steps, int* rest_tile0, int* rest_pre) {
+    Tn8Plan pl{};
+    const int cus = num_cus(), tiles_m = d.H / TN8_BM;
+    pl.grid = cus;
+    if (n_al) {
+        pl.al_tiles = tiles_m * tn8_cdiv(p[0].N, TN8_BN);
+        const int steps = p[0].rows / TN8_BK;
+        int S = cus / pl.al_tiles; if (S < 1) S = 1;
+        while (S > 1 && steps / S < 8) --S;                        // at least 8 k-steps per chunk
+        pl.S = S; pl.al_wgs = pl.al_tiles * S;
+        if (pl.al_wgs > pl.grid) pl.grid = pl.al_wgs;
+    } else { pl.S = 1; pl.al_wgs = 0; pl.al_tiles = 0; }
+    long long g = 0; int t0 = 0;
+    for (int i = 0; i < TN8_MAX_PROB; ++i) { rest_tiles[i] = 0; rest_steps[i] = 1; rest_tile0[i] = 0; rest_pre[i] = 0; }
+    for (int i = n_al; i < np; ++i) {
+        rest_tiles[i] = tiles_m * tn8_cdiv(p[i].N, TN8_BN); rest_steps[i] = p[i].rows / TN8_BK; rest_tile0[i] = t0; rest_pre[i] = (int)g;
+        t0 += rest_tiles[i]; g += (long long)rest_tiles[i] * rest_steps[i];
+    }
+    for (int i = np; i <= TN8_MAX_PROB; ++i) rest_pre[i] = (int)g;
+    for (int i = 0; i < n_al; ++i) rest_pre[i] = 0;
+    pl.rest_tiles_total = t0;
+    pl.R = g > 0 ? tn8_cdiv(g, pl.grid) : 1;
+    pl.n_slots = pl.al_wgs + t0 + pl.grid;
+    return pl;
+}
+
+// Slab bytes for the problems backward_impl hands to this kernel (worst case over the lesion flags: the a_other column block joins
+// the rest sequence when the answer-embedding segment is lesioned)
+size_t dw_tn8_slab_bytes(const ncx_dims& d) {
+    if (!dw_tn8_supported(d)) return 0;
+    const int cus = num_cus(), tiles_m = d.H / TN8_BM;
+    const bool aemb = d.flags & NCX_F_A_EMB;
+    long long al_wgs = 0;
+    if (aemb) { const int t = tiles_m * tn8_cdiv(d.A, TN8_BN); int S = cus / t; if (S < 1) S = 1; al_wgs = (long long)t * S; }
+    long long rest_tiles = 0;
+    const int cols[7] = {aemb ? 0 : d.da, d.dz, pad_to(d.K + 1, 4), d.dv, d.dq, d.dz, d.da};
+    for (int i = 0; i < 7; ++i) if (cols[i]) rest_tiles += (long long)tiles_m * tn8_cdiv(cols[i], TN8_BN);
+    const long long grid = al_wgs > cus ? al_wgs : cus;
+    return (size_t)(al_wgs + rest_tiles + grid) * TN8_BM * TN8_BN * 4;
+}
+
+static int tn8_fill(const ncx_dims& d, const Tn8Prob* probs, int np, int n_al, bool do_al, bool do_rest, Tn8Args& a, Tn8ReduceArgs& r,
+                    float* slab, size_t slab_bytes, Tn8Plan& pl) {
+    if (np < 1 || np > TN8_MAX_PROB || n_al < 0 || n_al > 1 || n_al > np) return NCX_E_DIMS;
+    for (int i = 0; i < np; ++i) {
+        if (probs[i].rows % TN8_BK || probs[i].N < 4 || probs[i].N % 4 || probs[i].ldx % 4) return NCX_E_DIMS;
+        if (probs[i].gsel && probs[i].rows != d.B) return NCX_E_DIMS;
+        a.p[i] = probs[i]; r.p[i] = probs[i];
+    }
+    pl = tn8_plan(d, probs, np, n_al, a.rest_tiles, a.rest_steps, a.rest_tile0, a.rest_pre);
+    if ((size_t)pl.n_slots * TN8_BM * TN8_BN * 4 > slab_bytes) return NCX_E_WORKSPACE;
+    // pieces per workgroup: the aligned chunk + every tile boundary its rest range can cross
+    int min_steps = 1 << 30;
+    for (int i = n_al; i < np; ++i) min_steps = a.rest_steps[i] < min_steps ? a.rest_steps[i] : min_steps;
+    if (np > n_al && 1 + pl.R / min_steps + 2 > TN8_MAX_SEG) return NCX_E_DIMS;
+    a.np = np; a.n_al = n_al; a.H = d.H; a.tiles_m = d.H / TN8_BM; a.B = d.B;
+    a.S = pl.S; a.al_wgs = pl.al_wgs; a.al_tiles_n = n_al ? tn8_cdiv(probs[0].N, TN8_BN) : 0; a.R = pl.R;
+    a.do_al = do_al && n_al; a.do_rest = do_rest && np > n_al;
+    a.slab = slab; a.n_slots = pl.n_slots;
+    r.np = np; r.n_al = n_al; r.tiles_m = a.tiles_m; r.S = pl.S; r.al_wgs = pl.al_wgs; r.R = pl.R; r.do_al = a.do_al; r.do_rest = a.do_rest;
+    for (int i = 0; i < TN8_MAX_PROB; ++i) { r.rest_tiles[i] = a.rest_tiles[i]; r.rest_steps[i] = a.rest_steps[i]; r.rest_tile0[i] = a.rest_tile0[i]; }
+    for (int i = 0; i <= TN8_MAX_PROB; ++i) r.rest_pre[i] = a.rest_pre[i];
+    r.al_tiles = pl.al_tiles; r.slab = slab;
+    r.n_tiles_total = (a.do_al ? pl.al_tiles : 0) + (a.do_rest ? pl.rest_tiles_total : 0);
+    return NCX_OK;
+}
+
+// Launch the products; the fixed-order sums are handed back in `red` (n_tiles_total == 0: nothing to reduce)
+int dw_tn8_products(const ncx_dims& d, const Tn8Prob* probs, int np, int n_al, bool do_al, bool do_rest, const int* idx_ob, const int* aid,
+                    float* slab, size_t slab_bytes, Tn8ReduceArgs* red, hipStream_t s) {
+    Tn8Args a{}; Tn8ReduceArgs r{}; Tn8Plan pl;
+    int rc = tn8_fill(d, probs, np, n_al, do_al, do_rest, a, r, slab, slab_bytes, pl);
+    if (rc) return rc;
+    *red = r;
+    if (!a.do_al && !a.do_rest) { red->n_tiles_total = 0; return NCX_OK; }
+    a.idx_ob = idx_ob; a.aid = aid;
+    const int lds = 2 * TN8_BK * (TN8_PA + TN8_PB) * 4 + TN8_MAX_SEG * (int)sizeof(Tn8Seg) + 2 * d.B * 4;
+    static DevMask attr{0};
+    NCX_HIP_TRY(set_max_lds_once(attr, (const void*)k_dw_tn8, 2 * TN8_BK * (TN8_PA + TN8_PB) * 4 + TN8_MAX_SEG * (int)sizeof(Tn8Seg) + 2 * 4096 * 4));
+    hipLaunchKernelGGL(k_dw_tn8, dim3(pl.grid), dim3(TN8_T), lds, s, a);
+    NCX_HIP_TRY(hipGetLastError());
+    return NCX_OK;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_dw_reduce_km_tn8(const KmReduceArgs km, const Tn8ReduceArgs tn) {
+    if ((int)blockIdx.x < km.nblk) { km_reduce_body<VEC>(km, blockIdx.x); return; }
+    tn8_reduce_body(tn, blockIdx.x - km.nblk);
+}
+
+int dw_reduce_km_tn8(const KmReduceArgs* km, bool km_vec, const Tn8ReduceArgs* tn, hipStream_t s) {
+    KmReduceArgs k0{}; Tn8ReduceArgs t0{};
+    if (km) k0 = *km;                                      // (nblk == 0: no fold slab)
+    if (tn) t0 = *tn;
+    const int nb = k0.nblk + t0.n_tiles_total * 8;
+    if (nb == 0) return NCX_OK;
+    if (km_vec) hipLaunchKernelGGL(k_dw_reduce_km_tn8<true>, dim3(nb), dim3(256), 0, s, k0, t0);
+    else        hipLaunchKernelGGL(k_dw_reduce_km_tn8<false>, dim3(nb), dim3(256), 0, s, k0, t0);
+    NCX_HIP_TRY(hipGetLastError());
+    return NCX_OK;
+}
+
+int dw_tn8(const ncx_dims& d, const Tn8Prob* probs, int np, int n_al, bool do_al, bool do_rest, const int* idx_ob, const int* aid,
+           float* slab, size_t slab_bytes, hipStream_t s) {
+    Tn8ReduceArgs r{};
+    int rc = dw_tn8_products(d, probs, np, n_al, do_al, do_rest, idx_ob, aid, slab, slab_bytes, &r, s);
+    if (rc) return rc;
+    return dw_reduce_km_tn8(nullptr, true, &r, s);
+}
+
+}  // namespace ncx

@@ -114,6 +114,23 @@ int dw_km(const ncx_dims& d, const float* dpre, const float* feats, const int* i
           float* g_vother, float* g_vmult, long long din, hipStream_t s, bool finish = true);
 int dw_km_finish(const ncx_dims& d, const float* slab, float* g_vother, float* g_vmult, long long din, const FixupArgs* fix, int fix_cfg,
                  hipStream_t s);
+// ncx_dwtn.hip: every other row-reduction product of linear_1's weight gradient (dGt, z_other, dist | rank, the per-triplet shared
+// segments) as one balanced launch of 8-wave workgroups on 256 x 64 tiles
+constexpr int TN8_MAX_PROB = 8;
+struct Tn8Prob {             // out[h][n] = sum_r A[r][h] * x(r, n)
+    const float* A;          // [rows][H]: dpre (rows = B K) or dSh (rows = B)
+    const float* X; long long ldx;   // operand rows, x(r, n) = X[row(r) * ldx + n]
+    const float* lse;        // non-NULL: x = exp2(X log2e - lse[r])   (softmax(a_knns), cx.py:281)
+    int gsel;                // row(r): 0 = r; 1 = idx_ob[r] (feature-table row of triplet r's original image); 2 = answer_aids[r]   (rows == B)
+    int rows, N;             // rows % 32 == 0; N % 4 == 0 (columns the operand rows hold)
+    float* out; long long ldo; int n_valid;      // columns written: n < n_valid <= N
+};
+bool dw_tn8_supported(const ncx_dims& d);
+size_t dw_tn8_slab_bytes(const ncx_dims& d);
+// problems [0, n_al) (n_al <= 1): tile-aligned row chunks, one per workgroup; [n_al, np): laid end to end and cut into equal ranges.
+// do_al / do_rest: which part this call launches (the chunking of each part does not depend on the other: phased backward)
+int dw_tn8(const ncx_dims& d, const Tn8Prob* probs, int np, int n_al, bool do_al, bool do_rest, const int* idx_ob, const int* aid,
+           float* slab, size_t slab_bytes, hipStream_t s);
 WsLayout ws_layout(const ncx_dims& d);
 __host__ __device__ static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 // The fused forward kernel (ncx_main.h) takes operands whose widths are multiples of 4 (16-byte windows, no straddling);
