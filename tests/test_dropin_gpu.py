@@ -240,8 +240,13 @@ def test_full_width_training_against_the_fp64_referee_and_heldout_recall():
         print("after %d steps: Recall@%d  HIP %.3f  fp32 CPU reference %.3f  fp64 referee %.3f  (%%; disagreeing triplets HIP/f64 %d, o32/f64 %d)"
               % (steps, k, rec["hip"], rec["o32"], rec["f64"], int(((R["hip"] < k) != (R["f64"] < k)).sum()), int(((R["o32"] < k) != (R["f64"] < k)).sum())))
         dis_h, dis_o = int(((R["hip"] < k) != (R["f64"] < k)).sum()), int(((R["o32"] < k) != (R["f64"] < k)).sum())
-        assert dis_h <= 2 * dis_o + 20, (k, dis_h, dis_o)
-        assert abs(int((R["hip"] < k).sum()) - int((R["f64"] < k).sum())) <= 3.0 * np.sqrt(max(dis_h, dis_o, 1)), (k, rec, dis_h, dis_o)
+        # Bounds that do not depend on the fp32 CPU run's luck (round 4; the 10-seed table profiles/r4_referee_table.json gives the
+        # distribution: HIP / f64 disagreements at k = 5 range 0 .. 141 with mean 67, the reference's own 0 .. 124 with mean 65):
+        # an absolute cap at ~mean + 3 sigma, and no bias beyond a symmetric random walk over the HIP run's own disagreements.
+        # The north_star's +-0.1 pt itself is asserted per seed at the 40-step horizon above and, at 200 steps, on the MEAN over
+        # the 10 seeds by tests/test_referee_table_cpu.py (-0.002 +- 0.067 pt at k = 5).
+        assert dis_h <= 200, (k, dis_h, dis_o)
+        assert abs(int((R["hip"] < k).sum()) - int((R["f64"] < k).sum())) <= 3.0 * np.sqrt(max(dis_h, 1)), (k, rec, dis_h, dis_o)
         if k == 5:
             assert rec["hip"] > 40.0, rec                                # learned (chance 20.8 %)
 
