@@ -131,6 +131,9 @@ size_t dw_tn8_slab_bytes(const ncx_dims& d);
 // do_al / do_rest: which part this call launches (the chunking of each part does not depend on the other: phased backward)
 int dw_tn8(const ncx_dims& d, const Tn8Prob* probs, int np, int n_al, bool do_al, bool do_rest, const int* idx_ob, const int* aid,
            float* slab, size_t slab_bytes, hipStream_t s);
+// ncx_mutan.hip: the rank-R fusion of the MUTAN producer as ONE product per question against an effective weight tile built on the fly
+bool mutan_fold_supported(const ncx_dims& d, const ncx_mutan_params& m);
+int mutan_fold(const ncx_dims& d, const ncx_mutan_params& m, const float* xv, const float* hq, float* z_orig, float* z_knns, hipStream_t s);
 WsLayout ws_layout(const ncx_dims& d);
 __host__ __device__ static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 // The fused forward kernel (ncx_main.h) takes operands whose widths are multiples of 4 (16-byte windows, no straddling);
