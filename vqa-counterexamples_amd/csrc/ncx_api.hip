@@ -1767,7 +1767,15 @@ int ncx_adam_step(float* param, const float* grad, float* exp_avg, float* exp_av
 }
 
 // ---- fused MUTAN producer ---------------------------------------------------------------------------
-struct VqaLayout { size_t xq, hq, xv, slab, slab_bytes, total; };
+struct VqaLayout { size_t xq, hq, xv, wcp, slab, slab_bytes, total; };
+// dst[r][0 .. cols) = src[r][0 .. cols), dst[r][cols .. ldd) = 0: the classifier weights with their rows zero-padded to whole 32-column
+// k-steps for the fused forward kernel (ncx_main.h reads the weight side of a segment up to the next multiple of 32 columns)
+__global__ __launch_bounds__(256) void k_pad_rows(const float* __restrict__ src, long long lds_, int cols, float* __restrict__ dst, int ldd, int rows) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)rows * ldd) return;
+    const int r = (int)(i / ldd), c = (int)(i - (long long)r * ldd);
+    dst[i] = c < cols ? src[(long long)r * lds_ + c] : 0.f;
+}
 static VqaLayout vqa_layout(const ncx_dims& d, const ncx_mutan_params& m, GemmPlan* plans /*[5]*/) {
     VqaLayout w{};
     size_t off = 0;
@@ -1776,6 +1784,7 @@ static VqaLayout vqa_layout(const ncx_dims& d, const ncx_mutan_params& m, GemmPl
     w.xq = take((size_t)d.B * m.dhq * 4);
     w.hq = take((size_t)d.B * RZ * 4);
     w.xv = take((size_t)Mv * m.dhv * 4);
+    w.wcp = take(d.dz % 32 ? (size_t)d.A * pad_to(d.dz, 32) * 4 : 0);
     // 0: xq = act(q Wq^T)  1: hq = xq Whq^T  2: xv = act(gather(v) Wv^T)  3: z (fold, never split)  4: a = z Wc^T
     const long long shp[5][3] = {{d.B, m.dhq, ks(d.dq)}, {d.B, RZ, ks(m.dhq)}, {Mv, m.dhv, ks(d.dv)}, {Mv, d.dz, 0}, {(long long)d.B * d.K, d.A, ks(d.dz)}};
     long long slab = 0;
@@ -1869,6 +1878,22 @@ int ncx_vqa_forward(const ncx_dims* dp, const float* feats, const int32_t* img_i
         a.epi.rowsplit_g = d.K + 1; a.epi.out0 = z_orig; a.epi.ldo0 = d.dz;
         rc = run_gemm_nt_fold(a, s); if (rc) return rc;
     }
+    if (d.dz % 4 == 0 && d.dz >= 4 && d.A % 4 == 0 && !hook_env("NCX_VQA_NO_MAIN")) {      // (the kernel's epilogue wants whole 16-byte pieces per output row)
+        // a_knns = z_knns . Wc^T + bc on the fused forward kernel (round 4): 11-12 k-steps per workgroup -> 64 x 64 tiles at three
+        // workgroups per CU (the plan the answer-embedding gradient takes); generic engine: 241 us at configs[2]          noatt.py:24-29
+        const float* wc = m.wc; long long ldw = d.dz;
+        if (d.dz % 32) {
+            float* wcp = (float*)(ws + w.wcp);
+            const int ldd = pad_to(d.dz, 32);
+            hipLaunchKernelGGL(k_pad_rows, dim3((unsigned)cdiv((long long)d.A * ldd, 256)), dim3(256), 0, s, m.wc, (long long)d.dz, d.dz, wcp, ldd, d.A);
+            NCX_HIP_TRY(hipGetLastError());
+            wc = wcp; ldw = ldd;
+        }
+        MainArgs a{}; a.M = d.B * d.K; a.N = d.A; a.nseg = 1;
+        a.seg[0].kind = MK_PLAIN; a.seg[0].a = z_knns; a.seg[0].lda = d.dz; a.seg[0].klen = d.dz; a.seg[0].b = wc; a.seg[0].ldb = ldw;
+        a.out = a_knns; a.ldo = d.A; a.epi.bias = m.bc; a.split = 1;
+        rc = main_forward(a, s); if (rc) return rc;
+    } else
     {   // a_knns = z_knns . Wc^T + bc                                               noatt.py:24-29 (dropout off in eval)
         GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = d.B * d.K;
         a.a[0] = x_plain(z_knns, d.dz, d.B * d.K, d.dz); a.b[0] = x_plain(m.wc, d.dz, d.A, d.dz); a.klen[0] = d.dz;

@@ -6,6 +6,7 @@ namespace ncx {
 typedef MainCfg<48, 128, 1, 4, 2, 2> MainCfg0;      // two workgroups per CU, 48 x 128 tiles (2 triplets at K = 24), loads two k-steps ahead
 typedef MainCfg<96, 64, 2, 2, 1, 2> MainCfg1;
 typedef MainCfg<96, 128, 2, 2, 2, 1> MainCfg2;      // one workgroup per CU with the whole register file
+typedef MainCfg<160, 128, 2, 2, 2, 1> MainCfgW;     // one workgroup per CU, 160 x 128: for single-segment products whose 96-row tiles fill the chip badly (x_v of the MUTAN producer)
 typedef MainCfg<64, 64, 2, 2, 2, 3> MainCfg3;       // short chains (the answer-embedding gradient: 16 k-steps): three small workgroups per CU
 typedef MainCfg<48, 64, 1, 4, 2, 2> MainCfgFold;    // MK_VFOLD sequences: 48 x 64 tiles (two triplets), two workgroups per CU
 typedef MainCfg<96, 64, 2, 2, 2, 2> MainCfgFold4;   // MK_VFOLD sequences: 96 x 64 tiles (four triplets share the W_k | W_m tiles), two workgroups per CU
@@ -32,6 +33,13 @@ int main_forward(MainArgs& a, hipStream_t s) {
     if (a.split <= 1 && T <= 32 && (long long)((a.M + 63) / 64) * ((a.N + 63) / 64) >= 2 * num_cus() && !hook_env("NCX_MAIN_CFG"))
         return launch_main_fwd<MainCfg3>(a, s);          // a workgroup that short spends as long starting and storing as multiplying: more of them per CU
     const long long tiles96 = (long long)((a.M + 95) / 96) * ((a.N + 127) / 128);
+    if (a.split <= 1 && a.nseg == 1 && a.seg[0].kind == MK_GATHER && !hook_env("NCX_MAIN_CFG")) {
+        // x_v of the MUTAN producer at configs[2]: 12 800 x 360 outputs = 402 tiles of 96 x 128 = 1.57 rounds of the one-per-CU slots (the second
+        // round 57 % full); 160-row tiles: 240 workgroups, ONE round
+        const long long cus = num_cus(), tiles160 = (long long)((a.M + 159) / 160) * ((a.N + 127) / 128);
+        const double e96 = (double)tiles96 / (double)(((tiles96 + cus - 1) / cus) * cus), e160 = (double)tiles160 / (double)(((tiles160 + cus - 1) / cus) * cus);
+        if (tiles160 * 10 >= cus * 7 && e160 > e96 + 0.1) return launch_main_fwd<MainCfgW>(a, s);
+    }
     int cfg = (a.split <= 1 && tiles96 * 10 >= (long long)num_cus() * 9) ? 2 : 0;
     if (const char* e = hook_env("NCX_MAIN_CFG")) cfg = atoi(e);       // experiment hook (NCX_EXPERIMENT=1)
     if (cfg == 1) return launch_main_fwd<MainCfg1>(a, s);

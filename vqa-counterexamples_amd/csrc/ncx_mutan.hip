@@ -41,61 +41,74 @@ __global__ __launch_bounds__(MF_TH, 1) void k_mutan_fold(const MutanFoldArgs a) 
     float* const lds_w = mfs + 2 * Q * 32 * P;             // [2][Q][J][P]
     float* const lds_h = mfs + 2 * Q * (32 + J) * P;       // [RMAX][J][Q]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
-    // question groups of one XCD run their column tiles back to back (the group's x_v rows stay in that L2)
+    // Workgroup ids are dealt round-robin over the 8 XCDs (id & 7), each with its own 4 MB L2.  Column-tile major inside an XCD: the
+    // workgroups resident together then share a few Whv slices (R x 32 x dhv floats each, the operand every question needs) instead of
+    // cycling all of Whv (5.2 MB at configs[2]) through every L2
     const int id = blockIdx.x, xcd = id & 7, local = id >> 3;
-    const int tj = local % a.tiles_j, g = (local / a.tiles_j) * 8 + xcd;
-    if (g >= a.groups) return;
+    const int gpx = (a.groups + 7) >> 3;                    // question groups per XCD
+    const int tj = local / gpx, g = (local - tj * gpx) * 8 + xcd;
+    if (g >= a.groups || tj >= a.tiles_j) return;
     const int q0 = g * Q, j0 = tj * J;
     const int nst = (a.dhv + KS - 1) / KS;
 
     // ---- roles ---------------------------------------------------------------------------------------------------------------------
-    // effective-weight build: thread = (column jl, k-quad kq) of the 32 x 32 tile, for questions 4 half .. 4 half + 3
-    const int pair = tid & 255, half = tid >> 8, jl = pair >> 3, kq = pair & 7;
+    // Waves 0-3 BUILD the effective weights: thread = (column jl, k-quad kq) of the 32 x 32 tile; it requests its R Whv quads once and forms
+    // the tile of all 8 questions from them.  Waves 4-7 stage the x_v rows (8 questions x 32 rows x 8 quads, 8 per thread).  (First version:
+    // every thread built 4 questions, so each Whv quad was requested by two threads: 112 KB per workgroup and k-step through a texture
+    // path that delivers ~35 GB/s per CU -- 125 us; one SIMD = one builder wave + one stager wave, so the two roles stay balanced.)
+    const bool builder = __builtin_amdgcn_readfirstlane(tid >> 6) < 4;
+    const int lt = tid & 255, jl = lt >> 3, kq = lt & 7;
     const int jc = min(j0 + jl, a.dz - 1);
-    // the workgroup's hq factors in LDS as [rank][column][question]: a build thread reads its four questions of one (rank, column) with one
-    // 16-byte load (kept in registers they cost 40 VGPRs and the kernel spilled)
+    // the workgroup's hq factors in LDS as [rank][column][question]: a build thread reads the eight questions of one (rank, column) with two
+    // 16-byte loads (kept in registers they cost 40+ VGPRs and the kernel spilled)
     for (int i = tid; i < RMAX * J * Q; i += T) {
         const int q = i % Q, jx = (i / Q) % J, rr = i / (Q * J);
         const int b = min(q0 + q, a.B - 1), jj = min(j0 + jx, a.dz - 1);
         lds_h[i] = rr < a.R ? a.hq[(long long)b * a.ld_hq + (long long)rr * a.dz + jj] : 0.f;
     }
-    // Whv addresses = uniform base of the rank (scalar registers) + one 32-bit lane offset: ten 64-bit lane pointers would not fit
-    const unsigned woff = (unsigned)jc * (unsigned)a.dhv;                      // rank rr: + rr dz dhv (ranks beyond R re-read the last one, times 0)
-    const long long wstride = (long long)a.dz * a.dhv;
-    // x_v rows: 8 questions x 32 rows x 8 quads = 2048 quads, 4 per thread: row f >> 3 of the tile, quad f & 7
-    mf_gfptr pa[4];
+    // one pointer per load slot; builders: rank i of Whv (ranks beyond R re-read the last one, times hq = 0); stagers: x_v row (lt + 256 i) >> 3
+    mf_gfptr pl[RMAX];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = tid + T * i, row = f >> 3, q = row >> 5, ri = row & 31;
+    for (int i = 0; i < RMAX; ++i) {
+        const int f = lt + 256 * min(i, 7), row = f >> 3, q = row >> 5, ri = row & 31;
         const long long r = (long long)min(q0 + q, a.B - 1) * a.K1 + min(ri, a.K1 - 1);
-        pa[i] = (mf_gfptr)a.xv + r * a.dhv;
+        pl[i] = builder ? (mf_gfptr)a.whv + ((long long)min(i, a.R - 1) * a.dz + jc) * a.dhv : (mf_gfptr)a.xv + r * a.dhv;
     }
-    const int aq = tid & 7;
-    f32x4 vw[RMAX], va[4];
-    auto issue = [&](int t) __attribute__((always_inline)) {
-        const int tt = min(t, nst - 1);
-        const int cw = min(tt * KS + 4 * kq, a.dhv - 4), ca = min(tt * KS + 4 * aq, a.dhv - 4);
+    // TWO register sets of global loads in flight: tile t + 1 (requested during step t - 1) is built while tile t + 2 is on its way
+    f32x4 vr[2][RMAX];
+    auto issue = [&](auto set_c, int t) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_c)::value;
+        const int c = min(min(t, nst - 1) * KS + 4 * kq, a.dhv - 4);         // (both roles: the thread's 16-byte k-quad is lt & 7)
 #pragma unroll
-        for (int rr = 0; rr < RMAX; ++rr) vw[rr] = *(mf_gf4ptr)((mf_gfptr)a.whv + min(rr, a.R - 1) * wstride + (woff + (unsigned)cw));
+        for (int i = 0; i < 8; ++i) vr[S][i] = *(mf_gf4ptr)(pl[i] + c);
+        if (builder) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) va[i] = *(mf_gf4ptr)(pa[i] + ca);
+            for (int i = 8; i < RMAX; ++i) vr[S][i] = *(mf_gf4ptr)(pl[i] + c);
+        }
     };
     // the tile of k-step t from the registers -> LDS buffer buf (columns beyond dhv: zero effective weights; dhv % 4 == 0)
-    auto build = [&](int t, int buf) __attribute__((always_inline)) {
-        const float keep = t * KS + 4 * kq < a.dhv ? 1.f : 0.f;
-        f32x4 w4[4];
+    auto build = [&](auto set_c, int t, int buf) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_c)::value;
+        if (builder) {
+            const float keep = t * KS + 4 * kq < a.dhv ? 1.f : 0.f;
 #pragma unroll
-        for (int rr = 0; rr < RMAX; ++rr) {
-            const f32x4 h4 = *(const f32x4*)(lds_h + (rr * J + jl) * Q + 4 * half);       // hq_rr[question 4 half + 0..3][column]
+            for (int hf = 0; hf < 2; ++hf) {                 // questions 4 hf .. 4 hf + 3
+                f32x4 w4[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+                for (int rr = 0; rr < RMAX; ++rr) {
+                    const f32x4 h4 = *(const f32x4*)(lds_h + (rr * J + jl) * Q + 4 * hf);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) w4[q][e] = rr == 0 ? h4[q] * vw[rr][e] : __builtin_fmaf(h4[q], vw[rr][e], w4[q][e]);
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w4[q][e] = rr == 0 ? h4[q] * vr[S][rr][e] : __builtin_fmaf(h4[q], vr[S][rr][e], w4[q][e]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *(f32x4*)(lds_w + ((buf * Q + 4 * hf + q) * J + jl) * P + 4 * kq) = w4[q] * keep;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *(f32x4*)(lds_a + (buf * Q * 32 + ((lt + 256 * i) >> 3)) * P + 4 * kq) = vr[S][i];
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) *(f32x4*)(lds_w + ((buf * Q + 4 * half + q) * J + jl) * P + 4 * kq) = w4[q] * keep;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { const int f = tid + T * i; *(f32x4*)(lds_a + (buf * Q * 32 + (f >> 3)) * P + 4 * aq) = va[i]; }
     };
 
     f32x4 acc[2][2];
@@ -119,23 +132,28 @@ __global__ __launch_bounds__(MF_TH, 1) void k_mutan_fold(const MutanFoldArgs a) 
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
         }
     };
-    issue(0);
+    typedef std::integral_constant<int, 0> S0; typedef std::integral_constant<int, 1> S1;
+    issue(S0{}, 0);
+    issue(S1{}, 1);
     __syncthreads();                                       // (the hq table)
-    build(0, 0);
-    issue(1);
+    build(S0{}, 0, 0);
+    issue(S0{}, 2);
     __syncthreads();
-#pragma unroll 1
-    for (int t = 0; t < nst; ++t) {
-        // the matrix cores multiply tile t while the vector ALU builds tile t + 1 from the registers that landed during step t - 1
-        mfma_step(t & 1);
+    // step t: the matrix cores multiply tile t (LDS buffer t & 1) while the vector ALU builds tile t + 1 from the register set that was
+    // requested during step t - 1, then requests tile t + 3 into it
+    auto step = [&](auto par_c, int t) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_c)::value;
+        typedef std::integral_constant<int, PAR ^ 1> SS;
+        mfma_step(PAR);
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 1 < nst) {
-            build(t + 1, (t + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);               // (the loads of tile t + 2 reuse the registers the build has just consumed)
-            issue(t + 2);
-        }
+        build(SS{}, t + 1, PAR ^ 1);                        // (beyond the last tile: a copy of it into the buffer nobody reads again)
+        __builtin_amdgcn_sched_barrier(0);                   // (the loads of tile t + 3 reuse the registers the build has just consumed)
+        issue(SS{}, t + 3);
         __syncthreads();
-    }
+    };
+    int t = 0;
+    for (; t + 1 < nst; t += 2) { step(S0{}, t); step(S1{}, t + 1); }
+    if (t < nst) step(S0{}, t);
     // ---- epilogue: + c_q[j], rows -> z_orig (image 0) / z_knns (images 1 .. K) ------------------------------------------------------------
     const int b = q0 + wave;
     if (b >= a.B) return;
@@ -143,8 +161,14 @@ __global__ __launch_bounds__(MF_TH, 1) void k_mutan_fold(const MutanFoldArgs a) 
     for (int j = 0; j < 2; ++j) {
         const int n = j0 + 16 * j + li;
         if (n >= a.dz) continue;
+        // c_q[n] = sum_rr hq_rr[q][n] bhv_rr[n]: the hq factors are in LDS, the R bias values are requested together (a load per iteration
+        // of a runtime-length loop is a dependent round trip per rank: 10 x ~1 us at the end of every workgroup)
+        float bh[RMAX];
+#pragma unroll
+        for (int rr = 0; rr < RMAX; ++rr) bh[rr] = ((mf_gfptr)a.bhv)[(long long)min(rr, a.R - 1) * a.dz + n];
         float c = 0.f;
-        for (int rr = 0; rr < a.R; ++rr) c = __builtin_fmaf(a.hq[(long long)b * a.ld_hq + (long long)rr * a.dz + n], a.bhv[(long long)rr * a.dz + n], c);
+#pragma unroll
+        for (int rr = 0; rr < RMAX; ++rr) c = __builtin_fmaf(lds_h[(rr * J + 16 * j + li) * Q + wave], bh[rr], c);     // (ranks beyond R: hq = 0)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
