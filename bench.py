@@ -373,8 +373,9 @@ def main():
                          "(v_other and v_orig*v_other as one per-triplet fold where the plan says so), Sh / ReLU / Dropout epilogue; tile: %s"
                          % plans["MAIN"]["tile"],
                  "DW1C": "linear_1 weight gradient (all columns + dGt): k_dw_km (v_other + v_mult columns in one MFMA pass, per-triplet "
-                         "fold, 8 k-chunks) + seg_gemm TN %s grouped, %d-way aligned split-K (remaining columns), incl. reductions"
-                         % (plans["DW1C"]["tile"], plans["DW1C"]["ksplit"])}
+                         "fold, 8 k-chunks) + k_dw_tn8 (dGt and every other column block: one balanced launch of 8-wave workgroups on 256 x 64 "
+                         "tiles; shapes it does not cover: seg_gemm TN %s grouped) + their merged fixed-order reduction"
+                         % plans["DW1C"]["tile"]}
         peak = PEAK_F32_MFMA_TFLOPS
         if args.bf16:
             peak = PEAK_BF16_MFMA_TFLOPS

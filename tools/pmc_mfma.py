@@ -19,7 +19,7 @@ def load(d):
 a, b = load(sys.argv[1]), load(sys.argv[2])
 lines = []
 for k in sorted(a, key=lambda k: -sum(a[k].get("SQ_WAVE_CYCLES", [0]))):
-    if "gemm" not in k and "k_main_fwd" not in k and "k_dw_km" not in k:
+    if "gemm" not in k and "k_main_fwd" not in k and "k_dw_km" not in k and "k_dw_tn8" not in k and "k_dw_reduce" not in k and "k_mutan" not in k:
         continue
     m = lambda d, n: (sum(d[k][n]) / len(d[k][n])) if k in d and d[k].get(n) else float("nan")
     wc, busy, wi, ai = m(a, "SQ_WAVE_CYCLES") * 4, m(a, "SQ_VALU_MFMA_BUSY_CYCLES"), m(a, "SQ_WAIT_INST_ANY") * 4, m(a, "SQ_ACTIVE_INST_ANY") * 4

@@ -51,7 +51,9 @@ if bf16:
     out["DW1C"] = total([part(("k_dpre_to_bf16",)), part(("gemm_bf16_tn8_kernel",)) or part(("gemm_bf16_tn_kernel",)), part(("k_bf16_reduce_dwc",))])
 else:
     out["MAIN"] = total([part(("k_main_fwd", "MainCfg<96, 64")) or part(("k_main_fwd",))])
-    out["DW1C"] = total([part(("k_dw_km<",)), part(("seg_gemm_kernel<128, 64, false, false",)), part(("k_dw_km_reduce_fixup",))])
+    # round 4: the fold kernel + the balanced 8-wave TN launch (ncx_dwtn.hip) + their merged reduction; earlier builds: the grouped TN GEMM
+    out["DW1C"] = total([part(("k_dw_km<",)), part(("k_dw_tn8",)) or part(("seg_gemm_kernel<128, 64, false, false",)),
+                         part(("k_dw_reduce_km_tn8",)) or part(("k_dw_km_reduce_fixup",))])
 for name, pat in (("k_prep", ("k_prep",)), ("k_adam", ("k_adam",))):
     p = part(pat)
     if p:

@@ -669,11 +669,13 @@ struct EmbPrepArgs {
     int B, H, A, Hp4;
 };
 // `fix` (valid: blocks beyond a.B + a.tile0[3]): the deferred split fix-up of the dW1[:, a_other] GEMM (64 x 64 tiles) rides along
-__global__ __launch_bounds__(256) void k_emb_prep(const EmbPrepArgs a, const FixupArgs fix) {
+__global__ __launch_bounds__(256) void k_emb_prep(const EmbPrepArgs a, const FixupArgs fix, const Tn8ReduceArgs red) {
     __shared__ unsigned bits[NCX_SCATTER_MAX_B / 32 > 32 * 33 ? NCX_SCATTER_MAX_B / 32 : 32 * 33];     // scatter: id bitmap; transposes: a [32][33] tile
     if ((int)blockIdx.x >= a.B + a.tile0[3]) {
         const int id = blockIdx.x - (a.B + a.tile0[3]);
-        split_fixup_body<64, 64>(fix, id / 4, id % 4);
+        const int nfix = fix.valid ? fix.grid_x * 4 : 0;
+        if (id < nfix) split_fixup_body<64, 64>(fix, id / 4, id % 4);
+        else tn8_reduce_body(red, id - nfix);            // the partial tiles of the dW1[:, a_other] launch (ncx_dwtn.hip)
         return;
     }
     if ((int)blockIdx.x < a.B) {
@@ -965,6 +967,7 @@ WsLayout ws_layout(const ncx_dims& d) {
     w.dagt = w.dgt + H * d.A * 4;                       // dGgt[H][A] = one-hot(aid)^T dSh, transposed
     w.dgtT = take((size_t)2 * d.A * pad_to(d.H, 4) * 4);
     w.w1aT = take((size_t)2 * d.da * pad_to(d.H, 32) * 4);
+    w.dgtT2 = take(dw_tn8_supported(d) ? (size_t)pad_to(d.A, 32) * pad_to(d.H, 4) * 4 : 0);
     w.partial = take((size_t)NCX_PRELUDE_WAVES * H * 4 * 2 + (size_t)NCX_PRELUDE_WAVES * 4 + 256);     // (>= NCX_COLSUM_CHUNKS rows)
     GemmUse u[U_COUNT];
     list_uses(d, u);
@@ -1611,8 +1614,15 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
             // and the slab slots are numbered over the whole list): phases 5 | 2 launch its two parts separately, bit-identically.
             Tn8Prob tp[TN8_MAX_PROB]; int np = 0, n_al = 0;
             auto prob = [&](const float* A_, int rows, const float* X, long long ldx, const float* lse, int gsel, int N, float* out, long long ldo, int n_valid) {
+                tp[np] = Tn8Prob{};
                 Tn8Prob& q = tp[np++]; q.A = A_; q.rows = rows; q.X = X; q.ldx = ldx; q.lse = lse; q.gsel = gsel; q.N = N; q.out = out; q.ldo = ldo; q.n_valid = n_valid; };
-            if (aemb) { prob(dpre, M, in->a_knns, d.A, mx, 0, d.A, dgt, d.A, d.A); n_al = 1; }
+            if (aemb) {
+                prob(dpre, M, in->a_knns, d.A, mx, 0, d.A, dgt, d.A, d.A); n_al = 1;
+                if (emb_nt) {       // the reduction also writes dGt^T (what the dE product and the DP exchange read) and a private copy with
+                    // zero rows up to a multiple of 32 (the A operand of the dW1[:, a_other] = dGt . E launch below)
+                    tp[0].outT = dgtT; tp[0].outT2 = (float*)(ws + w.dgtT2); tp[0].ldT = Hp4; tp[0].padT2 = pad_to(d.A, 32) - d.A;
+                }
+            }
             else prob(dpre, M, in->a_knns, d.da, nullptr, 0, d.da, g->w1 + o.a_other, din, d.da);
             prob(dpre, M, in->z_knns, d.dz, nullptr, 0, d.dz, g->w1 + o.z_other, din, d.dz);
             prob(dpre, M, misc, w.ldm, nullptr, 0, w.ldm, g->w1 + o.v_dist, din, d.K + 1);
@@ -1668,12 +1678,24 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
         SideStream* ss = km_deferred ? side_stream() : nullptr;
         hipStream_t se = ss ? ss->s : s;
         FixupArgs fix_ak{};
+        Tn8ReduceArgs red_ak{};
+        const bool tn8_ak = dw_tn8_supported(d) && emb_nt && !ss;
         if (ss) { rc = side_fork(ss, s); if (rc) return rc; }
         const bool bf16e = d.flags & NCX_F_BF16;
         const Bf16Emb bm = bf16e ? bf16_emb_layout(d, ws + w.bf_emb) : Bf16Emb{};
         if (do2 && bf16e) {
             rc = prof_open(U_DW1AK, se); if (rc) return rc;
             rc = bf16_dw1ak(d, bm, dgt, g->w1, se); if (rc) return rc;
+            rc = prof_close(U_DW1AK, se); if (rc) return rc;
+        } else if (do2 && tn8_ak) {   // dW1[:, a_other][n][j] = sum_a dGt^T[a][n] E[a][j]: a row-reduction over the A answers on the 8-wave TN kernel
+            // (round 4; NN form on the generic engine: 39 us + fix-up for 2.46 GF).  Its A operand is the PRIVATE copy of dGt^T: under data
+            // parallelism the other copy is being summed over ranks in place while this runs.
+            Tn8Prob q{};
+            q.A = (const float*)(ws + w.dgtT2); q.rows = pad_to(d.A, 32); q.rows_valid = d.A; q.X = p->answer_embedding; q.ldx = d.da; q.N = d.da;
+            q.out = g->w1 + o.a_other; q.ldo = din; q.n_valid = d.da;
+            rc = prof_open(U_DW1AK, se); if (rc) return rc;
+            rc = dw_tn8_products(d, &q, 1, 0, false, true, nullptr, nullptr, slab, w.slab_bytes, &red_ak, se); if (rc) return rc;
+            if (!(do1 && emb_nt)) { rc = dw_reduce_km_tn8(nullptr, true, &red_ak, se); if (rc) return rc; red_ak.n_tiles_total = 0; }   // (else: rides in k_emb_prep's launch)
             rc = prof_close(U_DW1AK, se); if (rc) return rc;
         } else if (do2) {   // dW1[:, a_other][n][j] = sum_a dGt[n][a] E[a][j]
             GemmArgs a{}; a.mode = MODE_CHAIN; a.nseg = 1; a.M = H;
@@ -1689,7 +1711,7 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
             const float* srcs[3] = {dgt, p->w1 + o.a_other, p->w1 + o.a_gt};
             float* dsts[3] = {dgtT, w1akT, w1agtT};
             const long long ldss[3] = {d.A, din, din};
-            const int colss[3] = {d.A, d.da, d.da}, ldds[3] = {Hp4, Hp32, Hp32};
+            const int colss[3] = {tn8_ak ? 0 : d.A, d.da, d.da}, ldds[3] = {Hp4, Hp32, Hp32};      // (tn8: dGt^T came out of the reduction)
             int tiles = 0;
             for (int e = 0; e < 3; ++e) {
                 ea.src[e] = srcs[e]; ea.dst[e] = dsts[e]; ea.lds_[e] = ldss[e]; ea.cols[e] = colss[e]; ea.ldd[e] = ldds[e]; ea.dcols[e] = ldds[e];
@@ -1697,8 +1719,8 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
             }
             ea.tile0[3] = tiles;
             // (the dW1[:, a_other] GEMM above left its split fix-up to this launch)
-            hipLaunchKernelGGL(k_emb_prep, dim3(d.B + tiles + (fix_ak.valid ? fix_ak.grid_x * 4 : 0)), dim3(256), 0, se, ea, fix_ak);
-            fix_ak.valid = 0;
+            hipLaunchKernelGGL(k_emb_prep, dim3(d.B + tiles + (fix_ak.valid ? fix_ak.grid_x * 4 : 0) + red_ak.n_tiles_total * 8), dim3(256), 0, se, ea, fix_ak, red_ak);
+            fix_ak.valid = 0; red_ak.n_tiles_total = 0;
             NCX_HIP_TRY(hipGetLastError());
         } else if (do1) {   // dGgt = one-hot(aid)^T dSh   (dGgt was cleared by k_bwd_prelude)
             hipLaunchKernelGGL(k_scatter_dsh_by_answer, dim3(d.B), dim3(256), 0, se, (const float*)dsh, in->answer_aids, d.B, H, d.A, dagt);

@@ -61,6 +61,7 @@ __device__ __forceinline__ void tn8_reduce_body(const Tn8ReduceArgs& r, int blk)
     }
     const Tn8Prob& p = r.p[prob];
     const int tm = tile % r.tiles_m, tn = tile / r.tiles_m;
+    __shared__ float tn8_tt[32][TN8_BN + 1];                     // the block's 32 x 64 sums, for the transposed copies
     // 32 rows x 64 columns = 512 float4: two per thread
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -78,6 +79,25 @@ __device__ __forceinline__ void tn8_reduce_body(const Tn8ReduceArgs& r, int blk)
         float* o = p.out + (long long)h * p.ldo + n;
 #pragma unroll
         for (int j = 0; j < 4; ++j) if (n + j < p.n_valid) o[j] = sum[j];      // (rows of linear_1.weight are din floats apart: not 16-byte aligned in general)
+        if (p.outT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) tn8_tt[f >> 4][c + j] = sum[j];
+        }
+    }
+    if (p.outT) {            // out^T[n][h]: thread = (column n = tid >> 2, 8 consecutive h): 32-byte pieces of 128-byte row segments
+        __syncthreads();
+        const int nl = threadIdx.x >> 2, hq = (threadIdx.x & 3) * 8;
+        const int n = tn * TN8_BN + nl, h0 = tm * TN8_BM + rgp * 32 + hq;
+        if (n < p.n_valid + p.padT2) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = n < p.n_valid ? tn8_tt[hq + j][nl] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (n < p.n_valid) p.outT[(long long)n * p.ldT + h0 + j] = v[j];
+                if (p.outT2) p.outT2[(long long)n * p.ldT + h0 + j] = v[j];
+            }
+        }
     }
 }
 

@@ -64,7 +64,7 @@ struct Tn8Seg {
     int t0;                           // first k-step of the piece
     int vbeg, vend;                   // the piece's range in the workgroup's virtual step sequence
     int slot;                         // slab slot of the partial tile
-    int pad;
+    int rv;                           // operand rows that exist (X rows beyond: index clamped; A is zero there)
 };
 static_assert(sizeof(Tn8Seg) == TN8_SEG_WORDS * 4, "segment record");
 
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
             sg.x_ptr = (unsigned long long)(uintptr_t)p.X;
             sg.l_ptr = (unsigned long long)(uintptr_t)(p.lse ? p.lse : p.A);
             sg.ldx = (int)p.ldx; sg.soft = p.lse ? 1 : 0; sg.gsel = p.gsel;
-            sg.n0 = tn * BN; sg.ncl = p.N - 4; sg.t0 = t0; sg.vbeg = v; sg.vend = v + (t1 - t0); sg.slot = slot; sg.pad = 0;
+            sg.n0 = tn * BN; sg.ncl = p.N - 4; sg.t0 = t0; sg.vbeg = v; sg.vend = v + (t1 - t0); sg.slot = slot; sg.rv = p.rows_valid > 0 ? p.rows_valid : p.rows;
             if (n < TN8_MAX_SEG) segs[n++] = sg;
             v += t1 - t0;
         };
@@ -153,9 +153,9 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) va[S][i] = *(tn_gf4ptr)(ap + (long long)(8 * i) * a.H);
         const int r = (int)r0 + brow;
-        const long long xr = dn.gsel ? (long long)rgn : (long long)r;
+        const long long xr = dn.gsel ? (long long)rgn : (long long)min(r, dn.rv - 1);
         vb[S] = *(tn_gf4ptr)((tn_gfptr)(uintptr_t)dn.x_ptr + xr * dn.ldx + min(dn.n0 + 4 * bq, dn.ncl));
-        vl[S] = ((tn_gfptr)(uintptr_t)dn.l_ptr)[dn.soft ? r : 0];
+        vl[S] = ((tn_gfptr)(uintptr_t)dn.l_ptr)[dn.soft ? min(r, dn.rv - 1) : 0];
         vs[S] = dn.soft ? 1.f : 0.f;
         // the record of the next issue (read now, used one k-step from now)
         qi += (v + 1 >= dn.vend && qi + 1 < nseg) ? 1 : 0;

@@ -55,6 +55,7 @@ struct WsLayout {
     size_t dgt;                         // [H][A]
     size_t dagt;                        // dGgt [H][A]  (bf16 variant only; the fp32 path keeps it transposed, below)
     size_t dgtT;                        // fp32 path: dGt^T [A][Hp4] then dGgt^T [A][Hp4] (contiguous: the all-reduce bucket under DP); Hp4 = H up to a multiple of 4
+    size_t dgtT2;                       // private copy of dGt^T with zero rows up to a multiple of 32 (A operand of the dW1[:, a_other] launch, ncx_dwtn.hip)
     size_t w1aT;                        // fp32 path: W1[:, a_other]^T then W1[:, a_gt]^T, [da][Hp32] each (zero padded)
     size_t partial;                     // column-sum partials [NCX_COLSUM_CHUNKS][H] x 2 + scalars
     size_t slab;                        // split-K slabs (max over all uses)
@@ -124,6 +125,8 @@ struct Tn8Prob {             // out[h][n] = sum_r A[r][h] * x(r, n)
     int gsel;                // row(r): 0 = r; 1 = idx_ob[r] (feature-table row of triplet r's original image); 2 = answer_aids[r]   (rows == B)
     int rows, N;             // rows % 32 == 0; N % 4 == 0 (columns the operand rows hold)
     float* out; long long ldo; int n_valid;      // columns written: n < n_valid <= N
+    int rows_valid;          // 0: = rows.  Else operand rows >= rows_valid do not exist (their index is clamped) and A's rows there are ZERO
+    float* outT; float* outT2; long long ldT; int padT2;   // optional transposed copies out^T[n][h] (ld ldT); outT2 also gets padT2 zero rows after n_valid
 };
 bool dw_tn8_supported(const ncx_dims& d);
 size_t dw_tn8_slab_bytes(const ncx_dims& d);
