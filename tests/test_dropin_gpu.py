@@ -549,6 +549,33 @@ def test_hip_vqa_forward_full_dims_vs_torch_module():
     assert float((s_hip - s_ref).detach().abs().max()) <= 1e-4
 
 
+@pytest.mark.parametrize("B,dz,dhv,R,A", [(13, 44, 28, 4, 52), (8, 360, 360, 10, 100), (70, 32, 36, 1, 40)])
+def test_hip_vqa_forward_ragged_shapes_vs_oracle(B, dz, dhv, R, A):
+    """The effective-weight fusion kernel (csrc/ncx_mutan.hip: one product per question against sum_r diag(hq_r[q]) Whv_r) at shapes that
+    fill none of its tiles: batches that are not multiples of the 8 questions of a workgroup, dim_mm / dim_hv that are not multiples of the
+    32-column / 32-deep tiles (dim_hv = 28, 36: a partial last k-step), R = 1 and R < 10; the classifier then runs on the fused forward
+    kernel (A a multiple of 4) with zero-padded weight rows.  Reference: oracle.mutan_vqa_forward (fusion.py:78-121, noatt.py:24-29)."""
+    import vqa.models as M
+    from neuralcx import ops
+    torch.manual_seed(7 + B)
+    opt = dict(arch="MutanNoAtt", seq2vec=dict(arch="gru", emb_size=8, dropout=0.0),
+               fusion=dict(dim_v=96, dim_q=48, dim_hv=dhv, dim_hq=20, dim_mm=dz, R=R, dropout_v=0.5, dropout_q=0.5,
+                           activation_v="tanh", activation_q="tanh", dropout_hv=0, dropout_hq=0), classif=dict(dropout=0.5))
+    vqa = M.factory(opt, ["w%d" % i for i in range(10)], ["a%d" % i for i in range(A)], cuda=True, data_parallel=False).eval()
+    mw = ops.MutanWeights(vqa)
+    K1 = 25
+    feats = (torch.randn(B, K1, 96, device=DEV).abs() * 0.45)
+    q_emb = torch.randn(B, 48, device=DEV) * 0.5
+    idx = torch.arange(B * K1, device=DEV, dtype=torch.int32).view(B, K1)
+    hip = ops.vqa_forward(feats.reshape(B * K1, 96).contiguous(), idx, q_emb, mw, want_a_orig=True)
+    vp = {k: v.detach().cpu() for k, v in vqa.state_dict().items()}
+    ref = orc.mutan_vqa_forward(vp, feats.cpu(), q_emb.cpu(), R=R)
+    for h, r, nm in zip(hip, ref, ("a_orig", "z_orig", "a_knns", "z_knns")):
+        assert h.shape == r.shape, nm
+        err, mx = float((h.detach().cpu() - r).abs().max()), float(r.abs().max())
+        assert err <= 1e-4 * max(mx, 1e-3), (nm, err, mx)
+
+
 def test_module_is_reentrant_two_forwards_before_backward():
     """a second model(...) before loss.backward() -- an evaluation pass inside the train loop, exactly
     what counterexamples.py:357-361 does with eval_freq, or gradient accumulation -- must not disturb the first graph:

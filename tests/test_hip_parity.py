@@ -256,6 +256,39 @@ def test_lesion_flags_vs_oracle(spec):
     compare_with_oracle(d, full, params, batch, extra=extra)
 
 
+@pytest.mark.parametrize("case", ["all", "no_a_emb", "no_v_mult", "H512_L2", "K48", "dropout"])
+def test_balanced_tn_launch_paths_vs_oracle(case):
+    """The 8-wave balanced TN launch (csrc/ncx_dwtn.hip) takes dGt and every weight-gradient column block outside the per-triplet
+    fold whenever H is a multiple of 256 and the batch a multiple of 32 (>= 128): reduced widths keep the oracle fast, H and B
+    are the real ones.  Cases: the full model (aligned dGt part + rest sequence + the dW1[:, a_other] launch); the a_emb lesion (no
+    aligned part, the a_other block joins the rest sequence as a plain operand); the v_mult lesion (no fold kernel: the v columns
+    stay on the generic grouped launch next to the TN launch); H = 512 (two row tiles per column tile) with a hidden layer;
+    K = 48; train mode with the counter-based dropout.  B = 160 is not a multiple of the 8 row chunks' k-steps: ragged chunking."""
+    spec, extra, kw = None, {}, {}
+    d = orc.Dims(dv=96, dq=64, dz=24, A=40, H=256, L=1)
+    B = 160
+    if case == "H512_L2":
+        d = orc.Dims(dv=96, dq=64, dz=24, A=40, H=512, L=2); B = 128
+    if case == "K48":
+        d = orc.Dims(K=48, dv=96, dq=64, dz=24, A=40, H=256, L=1); B = 128
+    params = orc.init_params(d, seed=21, gain=3.0)
+    batch = random_case(2100 + len(case), B, d)
+    batch["answer_aids"][0] = batch["answer_aids"][B - 1]           # a duplicated answer id (owner-computes scatter)
+    if case == "no_a_emb":
+        torch.manual_seed(4)
+        batch["a_knns"] = torch.rand(B, d.K, d.da); extra["a_emb_gt"] = torch.rand(B, d.da)
+        spec = dict(orc.DEFAULT_SPEC, a_emb=False)
+    if case == "no_v_mult":
+        spec = dict(orc.DEFAULT_SPEC, v_mult=False)
+    if case == "dropout":
+        seed = 0x0BADC0FFEE
+        masks = [orc.dropout_keep_mask(seed, 1, B * d.K, d.H, 0.25)]
+        kw = dict(training=True, drop_p=0.25, masks=masks, seed=seed, use_rng=True)
+    from neuralcx import _lib
+    from neuralcx import ops
+    compare_with_oracle(d, spec, params, batch, extra=extra, **kw)
+
+
 def test_full_dims_property_checks():
     """BASELINE size (B=512, K=24, full widths, H=256): size-independent properties instead of the oracle.
     (1) row permutation equivariance of scores; (2) shifting all K logits of a row by a constant (out.bias)
