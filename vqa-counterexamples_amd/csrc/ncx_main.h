@@ -643,13 +643,6 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
     // epilogue with 16-byte operand loads and stores whole rows.
     constexpr int SP = BN + 4;
     float* const stage = mf_smem;                        // [BM][SP]  (every fragment read is complete: the last step's barrier)
-#pragma unroll
-    for (int i = 0; i < WM; ++i)
-#pragma unroll
-        for (int j = 0; j < WN; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) stage[(wm0 + 16 * i + 4 * lk + q) * SP + wn0 + 16 * j + li] = acc[i][j][q];
-    __syncthreads();
     constexpr int QR = BN / 4;                            // 16-byte pieces per tile row
     const EpiArgs& e = args.epi;
     float* const dst = S > 1 ? args.slab + (long long)z * M * N : args.out;      // S > 1: raw partial sums; k_main_fixup runs the epilogue
@@ -671,21 +664,32 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
     };
     const bool use_add = !plain && e.rowadd;
     const int rdiv = use_add ? e.rowdiv : 1;
-    f32x4 add_next = {0.f, 0.f, 0.f, 0.f};
-    {
-        int r, n, nl; item(tid, r, n, nl);
-        if (use_add) add_next = win(e.rowadd + (long long)(min(r, M - 1) / rdiv) * e.ld_rowadd, min(nl, max(N - 4, 0)), min(n, N - 1) - min(nl, max(N - 4, 0)));
-    }
+    // The row-add operand (Sh[r / K]) of piece f + 3 x MT is requested while piece f is finished: a FIFO of three (round 4).  With one
+    // piece of lookahead (rounds 2-3) every iteration of this rolled loop waited out most of an L2 round trip for the load the iteration
+    // before it had issued: in-kernel stamps put the epilogue at ~25 k cycles for six pieces per thread, ~10 us of a 270 us workgroup.
+    auto fetch_add = [&](int f) __attribute__((always_inline)) -> f32x4 {
+        int r2, n2, nl2; item(f, r2, n2, nl2);
+        const int n2c = min(n2, N - 1), nl2c = min(nl2, n2c);
+        return win(e.rowadd + (long long)(min(r2, M - 1) / rdiv) * e.ld_rowadd, nl2c, n2c - nl2c);
+    };
+    constexpr int LAST_F = BM * QR - 1;
+    f32x4 add0 = {0.f, 0.f, 0.f, 0.f}, add1 = add0, add2 = add0;
+    if (use_add) { add0 = fetch_add(min(tid, LAST_F)); add1 = fetch_add(min(tid + MT, LAST_F)); add2 = fetch_add(min(tid + 2 * MT, LAST_F)); }
+    // (the three requests above are in flight while the accumulators go through LDS)
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) stage[(wm0 + 16 * i + 4 * lk + q) * SP + wn0 + 16 * j + li] = acc[i][j][q];
+    __syncthreads();
 #pragma unroll 1
     for (int f = tid; f < BM * QR; f += MT) {
         int r, n, nl;
         const int so = item(f, r, n, nl);
-        const f32x4 addv = add_next;
-        if (use_add && f + MT < BM * QR) {
-            int r2, n2, nl2; item(f + MT, r2, n2, nl2);
-            const int n2c = min(n2, N - 1), nl2c = min(nl2, n2c);
-            add_next = win(e.rowadd + (long long)(min(r2, M - 1) / rdiv) * e.ld_rowadd, nl2c, n2c - nl2c);
-        }
+        const f32x4 addv = add0;
+        add0 = add1; add1 = add2;
+        if (use_add) add2 = fetch_add(min(f + 3 * MT, LAST_F));
         if (r >= M || n >= N) continue;
         f32x4 v = *(const f32x4*)(stage + so);
         const int sh = n - nl;
