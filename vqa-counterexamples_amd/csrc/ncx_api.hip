@@ -877,7 +877,8 @@ static void list_uses(const ncx_dims& d, GemmUse* u) {
         const bool km = dw_km_supported(d) && !(d.flags & NCX_F_BF16);     // v_other / v_mult columns: ncx_dwkm.hip
         const bool tn8 = dw_tn8_supported(d);                               // every other column block + dGt: ncx_dwtn.hip
         const long long segs_c[5] = {km ? 0 : d.dv, (!km && (d.flags & NCX_F_V_MULT)) ? d.dv : 0, tn8 ? 0 : d.K + 1, tn8 ? 0 : d.dz, tn8 ? 0 : (aemb ? d.A : d.da)};
-        const long long segs_s[5] = {tn8 ? 0 : d.dv, tn8 ? 0 : d.dq, tn8 ? 0 : d.dz, tn8 ? 0 : d.da, 0};
+        const bool tn8s = tn8 || dw_tn8_shapes_ok(d);                       // (the bf16 variant: its fp32 shared segments take the TN kernel too)
+        const long long segs_s[5] = {tn8s ? 0 : d.dv, tn8s ? 0 : d.dq, tn8s ? 0 : d.dz, tn8s ? 0 : d.da, 0};
         const bool grouped = i == U_DW1C || i == U_DW1S;
         auto grouped_tiles = [&](int bm, int bn) {
             const long long* sg = i == U_DW1C ? segs_c : segs_s;
@@ -933,7 +934,7 @@ static void list_uses(const ncx_dims& d, GemmUse* u) {
     u[U_DW1S].plan.cfg = u[U_DW1C].plan.cfg;
     {
         int bm, bn; cfg_tile(u[U_DW1C].plan.cfg, bm, bn);
-        const bool tn8 = dw_tn8_supported(d);
+        const bool tn8 = dw_tn8_shapes_ok(d);
         const long long segs_s[4] = {tn8 ? 0 : d.dv, tn8 ? 0 : d.dq, tn8 ? 0 : d.dz, tn8 ? 0 : d.da};
         const int S = u[U_DW1S].plan.split > 1 ? u[U_DW1S].plan.split : 1;
         u[U_DW1S].tiles = 0; u[U_DW1S].wgs = 0;
@@ -1650,6 +1651,18 @@ static int backward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_par
             add_c(x_plain(in->z_knns, d.dz, M, d.dz), g->w1 + o.z_other, din);
             add_c(x_plain(misc, w.ldm, M, d.K + 1), g->w1 + o.v_dist, din);
         }
+        if (want_rest && bf16 && dw_tn8_shapes_ok(d)) {      // bf16 variant: the fp32 shared segments' weight gradient on the balanced TN kernel
+            Tn8Prob tp[4]; int np = 0;
+            auto prob = [&](const float* X, long long ldx, int gsel, int N, float* out) {
+                tp[np] = Tn8Prob{};
+                Tn8Prob& q = tp[np++]; q.A = dsh; q.rows = d.B; q.X = X; q.ldx = ldx; q.gsel = gsel; q.N = N; q.out = out; q.ldo = din; q.n_valid = N; };
+            prob(in->feats, d.dv, 1, d.dv, g->w1 + o.v_orig);
+            prob(in->q_emb, d.dq, 0, d.dq, g->w1 + o.q_emb);
+            prob(in->z_orig, d.dz, 0, d.dz, g->w1 + o.z_orig);
+            if (aemb) prob(p->answer_embedding, d.da, 2, d.da, g->w1 + o.a_gt);
+            else      prob(in->a_emb_gt, d.da, 0, d.da, g->w1 + o.a_gt);
+            rc = dw_tn8(d, tp, np, 0, false, true, idx_ob, aemb ? in->answer_aids : nullptr, slab, w.slab_bytes, s); if (rc) return rc;
+        } else
         if (want_rest && !tn8) {
             add_s(x_gather(in->feats, d.dv, idx_ob, d.B, d.dv), g->w1 + o.v_orig);
             add_s(x_plain(in->q_emb, d.dq, d.B, d.dq), g->w1 + o.q_emb);

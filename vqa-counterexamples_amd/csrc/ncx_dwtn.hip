@@ -266,9 +266,10 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
 // ---- host ------------------------------------------------------------------------------------------------------------------------------
 static inline int tn8_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-bool dw_tn8_supported(const ncx_dims& d) {
+bool dw_tn8_supported(const ncx_dims& d) { return !(d.flags & NCX_F_BF16) && dw_tn8_shapes_ok(d); }
+// the bf16 variant keeps the per-triplet shared segments of linear_1 in fp32: their weight gradient takes this kernel too (rest sequence only)
+bool dw_tn8_shapes_ok(const ncx_dims& d) {
     if (hook_env("NCX_NO_TN8")) return false;
-    if (d.flags & NCX_F_BF16) return false;
     const long long M = (long long)d.B * d.K;
     // all of H in 256-row tiles; whole 32-row k-steps for both reduction extents; 16-byte operand windows; the per-triplet row-gather
     // tables fit in LDS; enough k-steps per chunk to be worth a pipeline (below that the generic engine's plans are as good)
@@ -307,13 +308,13 @@ static Tn8Plan tn8_plan(const ncx_dims& d, const Tn8Prob* p, int np, int n_al, i
 // Slab bytes for the problems backward_impl hands to this kernel (worst case over the lesion flags: the a_other column block joins
 // the rest sequence when the answer-embedding segment is lesioned)
 size_t dw_tn8_slab_bytes(const ncx_dims& d) {
-    if (!dw_tn8_supported(d)) return 0;
+    if (!dw_tn8_shapes_ok(d)) return 0;
     const int cus = num_cus(), tiles_m = d.H / TN8_BM;
-    const bool aemb = d.flags & NCX_F_A_EMB;
+    const bool aemb = d.flags & NCX_F_A_EMB, bf16 = d.flags & NCX_F_BF16;
     long long al_wgs = 0;
-    if (aemb) { const int t = tiles_m * tn8_cdiv(d.A, TN8_BN); int S = cus / t; if (S < 1) S = 1; al_wgs = (long long)t * S; }
+    if (aemb && !bf16) { const int t = tiles_m * tn8_cdiv(d.A, TN8_BN); int S = cus / t; if (S < 1) S = 1; al_wgs = (long long)t * S; }
     long long rest_tiles = 0;
-    const int cols[7] = {aemb ? 0 : d.da, d.dz, pad_to(d.K + 1, 4), d.dv, d.dq, d.dz, d.da};
+    const int cols[7] = {(aemb || bf16) ? 0 : d.da, bf16 ? 0 : d.dz, bf16 ? 0 : pad_to(d.K + 1, 4), d.dv, d.dq, d.dz, d.da};
     for (int i = 0; i < 7; ++i) if (cols[i]) rest_tiles += (long long)tiles_m * tn8_cdiv(cols[i], TN8_BN);
     const long long grid = al_wgs > cus ? al_wgs : cus;
     return (size_t)(al_wgs + rest_tiles + grid) * TN8_BM * TN8_BN * 4;

@@ -129,6 +129,7 @@ struct Tn8Prob {             // out[h][n] = sum_r A[r][h] * x(r, n)
     float* outT; float* outT2; long long ldT; int padT2;   // optional transposed copies out^T[n][h] (ld ldT); outT2 also gets padT2 zero rows after n_valid
 };
 bool dw_tn8_supported(const ncx_dims& d);
+bool dw_tn8_shapes_ok(const ncx_dims& d);          // ... ignoring the bf16 flag (the variant's fp32 shared segments)
 size_t dw_tn8_slab_bytes(const ncx_dims& d);
 // problems [0, n_al) (n_al <= 1): tile-aligned row chunks, one per workgroup; [n_al, np): laid end to end and cut into equal ranges.
 // do_al / do_rest: which part this call launches (the chunking of each part does not depend on the other: phased backward)
