@@ -690,7 +690,7 @@ def test_cli_resume_continues_bit_for_bit(tmp_path, capsys):
     assert len(torch.load(os.path.join(base, "info.ckpt"))) == 3
 
 
-def _dp_pipeline_worker(rank, world, port, q, pipeline):
+def _dp_pipeline_worker(rank, world, port, q, pipeline, H=64, Bg=12):
     import os, sys
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     from conftest import PKG, ROOT
@@ -699,8 +699,8 @@ def _dp_pipeline_worker(rank, world, port, q, pipeline):
     from neuralcx import dp, ops
     from neuralcx.engine import NeuralCXEngine
     dp.init_distributed(backend="gloo")
-    d = orc.Dims(dv=96, dq=64, dz=24, A=40, H=64, L=1)
-    Bg, steps = 12, 5
+    d = orc.Dims(dv=96, dq=64, dz=24, A=40, H=H, L=1)
+    steps = 5
     batch = _dp_batch(d, Bg * steps)
     eng = NeuralCXEngine(K=d.K, dv=d.dv, dq=d.dq, dz=d.dz, da=d.da, A=d.A, H=d.H, L=d.L, drop_p=0.25, lr=1e-3, device=DEV, world_size=world)
     eng.rank = rank
@@ -725,19 +725,21 @@ def _dp_pipeline_worker(rank, world, port, q, pipeline):
     dist.barrier(); dist.destroy_process_group()
 
 
-def test_dp2_pipelined_bucket2_is_bit_identical_to_the_unpipelined_engine():
+@pytest.mark.parametrize("H,Bg", [(64, 12), (256, 256)])
+def test_dp2_pipelined_bucket2_is_bit_identical_to_the_unpipelined_engine(H, Bg):
     """engine.pipeline (round 4): under data parallelism the wait for the LAST gradient bucket and the Adam slice it feeds are
     deferred to the next train_step, behind that step's data-only forward prelude (ncx_forward_phase PRELUDE: k_prep), so the
     exchange has the prelude to hide behind.  Same kernels, same operands, every dependency respected: after 5 steps with
     dropout on two ranks (gloo on one card) the weights, both Adam moments, every per-step loss and an evaluation taken between
-    two steps are BIT-identical to the unpipelined engine's, and the replicas are identical."""
+    two steps are BIT-identical to the unpipelined engine's, and the replicas are identical.  (H = 256 with 128 triplets per rank: the
+    phased backward then runs the balanced 8-wave TN launch in its two parts, csrc/ncx_dwtn.hip.)"""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     res = {}
     for pipeline in (True, False):
         q = ctx.Queue()
-        port = 29400 + os.getpid() % 200 + int(pipeline)
-        procs = [ctx.Process(target=_dp_pipeline_worker, args=(r, 2, port, q, pipeline)) for r in range(2)]
+        port = 29400 + os.getpid() % 200 + int(pipeline) + (2 if H == 256 else 0)
+        procs = [ctx.Process(target=_dp_pipeline_worker, args=(r, 2, port, q, pipeline, H, Bg)) for r in range(2)]
         [p.start() for p in procs]
         outs = [q.get(timeout=240), q.get(timeout=240)]
         [p.join(120) for p in procs]

@@ -542,10 +542,12 @@ def test_phased_forward_is_bit_identical(shape):
 def test_phased_backward_is_bit_identical():
     """ncx_backward_phase 1 then 2, and 3 then 4, == ncx_backward (what the data-parallel engine relies on)."""
     from neuralcx import ops
-    for L in (1, 2):
-        d = orc.Dims(dv=96, dq=64, dz=24, A=40, H=64, L=L)
+    # (H = 64, B = 20: the generic engine's grouped launch; H = 256, B = 128 / 160: the balanced 8-wave TN launch, whose aligned dGt part and
+    #  rest sequence are launched separately by phases 5 | 2 and together by phase 0 -- same chunking, same slab slots, same sums)
+    for L, H, B in ((1, 64, 20), (2, 64, 20), (1, 256, 128), (2, 256, 160)):
+        d = orc.Dims(dv=96, dq=64, dz=24, A=40, H=H, L=L)
         params = orc.init_params(d, seed=9, gain=3.0)
-        batch = random_case(31, 20, d)
+        batch = random_case(31, B, d)
         b = to_dev_batch(batch)
         p = to_dev_params(params)
         dims = ops.make_dims(b, H=d.H, L=d.L, da=d.da, A=d.A)
