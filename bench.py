@@ -158,7 +158,8 @@ def workload_label(args, c):
     if args.c3:
         return "configs[2]: fused HIP MUTAN producer (vqa_forward) + "
     if (args.batch, c["K"], c["H"], c["L"]) == (512, 24, 256, 1):
-        return "configs[1] shape, bf16-operand variant (NOT the headline): " if args.bf16 else "configs[1]: "
+        return ("configs[1] shape, bf16-operand variant (NOT the headline): " if args.bf16 else
+                "configs[1] with --x6 (NOT the headline): " if args.x6 else "configs[1]: ")
     if (args.batch, c["K"]) == (1024, 48):
         return ("configs[4] shape (48 candidates, batch 1024, bf16 operands), one GPU: " if args.bf16
                 else "configs[4] shape (48 candidates, batch 1024) in fp32, one GPU: ")
@@ -178,6 +179,7 @@ def main():
     ap.add_argument("--pool", type=int, default=4, help="distinct resident batches cycled through")
     ap.add_argument("--c3", action="store_true", help="configs[2]: z / answer logits produced per step by the fused HIP MUTAN (ncx_vqa_forward)")
     ap.add_argument("--bf16", action="store_true", help="configs[4] variant: bf16 MFMA operands for the two dominant GEMMs (NOT the headline: fp32 is)")
+    ap.add_argument("--x6", action="store_true", help="NCX_F_X6: the balanced TN weight-gradient launch on the bf16 matrix path with three-plane fp32-grade operands (NOT the headline: fp32 MFMA is)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=50, help="timed all-core steps of the CPU baseline (after 10 warm-up)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
@@ -224,7 +226,7 @@ def main():
         if args.batch % world:
             raise SystemExit("--scaling strong: --batch (%d) must be a multiple of the number of ranks (%d)" % (args.batch, world))
         args.batch //= world                          # per-rank share of the fixed global batch
-    eng = NeuralCXEngine(K=args.K, H=args.H, L=args.L, drop_p=0.25, lr=1e-4, device=dev, world_size=world, bf16=args.bf16)
+    eng = NeuralCXEngine(K=args.K, H=args.H, L=args.L, drop_p=0.25, lr=1e-4, device=dev, world_size=world, bf16=args.bf16, x6=args.x6)
     eng.rank = rank                                   # (per-rank dropout streams)
     eng.init_parameters(seed=42)                      # identical replicas on every rank
     data = SyntheticCX(n_triplets=args.batch * args.pool * world, K=args.K, n_img=args.n_img, seed=1234, device=dev)
@@ -377,6 +379,8 @@ def main():
                          "tiles; shapes it does not cover: seg_gemm TN %s grouped) + their merged fixed-order reduction"
                          % plans["DW1C"]["tile"]}
         peak = PEAK_F32_MFMA_TFLOPS
+        if args.x6:
+            names["DW1C"] += " [--x6: k_dw_tn8_x6 instead of k_dw_tn8 -- three bf16 planes per operand, six v_mfma_f32_16x16x32_bf16 per block; tflops / frac below stay fp32-equivalent against the fp32-MFMA peak]"
         if args.bf16:
             peak = PEAK_BF16_MFMA_TFLOPS
             names = {"MAIN": "gemm_bf16_nt (packed candidate rows . packed weights^T, fwd; 64x64 or 128x128 tiles by workgroup count; weight pack excluded)",
@@ -442,7 +446,8 @@ def main():
                    value=round(gb * args.steps / dt, 1), unit="triplets/s", n_gpus=world, steps=args.steps,
                    warmup=args.warmup, preheat_ms=args.preheat_ms, ms_per_step=round(dt / args.steps * 1e3, 4),
                    ms_per_step_no_preheat=ms_cold, higher_is_better=True,
-                   scaling=args.scaling, vs_baseline=None, dtype="bf16 operands / f32 accumulate (first-layer GEMMs), f32 elsewhere" if args.bf16 else "f32",
+                   scaling=args.scaling, vs_baseline=None, dtype="bf16 operands / f32 accumulate (first-layer GEMMs), f32 elsewhere" if args.bf16 else
+                         "f32; f32 via bf16x6 (three bf16 planes per operand, six products, f32 accumulate) in the balanced TN weight-gradient launch -- NOT the headline" if args.x6 else "f32",
                    data="synthetic",
                    config=dict(workload=workload_label(args, c) +
                                         "NeuralCX MLP train step (fwd+listwise loss/recall+bwd+Adam), synthetic "

@@ -65,6 +65,13 @@ extern "C" {
  * have run on the same workspace (its `dscores` may be NULL).  K <= 32 and H <= 256 only (ncx_train_tail says NCX_E_DIMS
  * otherwise: clear the bit and use the three calls). */
 #define NCX_F_FUSED_TAIL (1u << 6)
+/* Not the default (the headline path is fp32 MFMA): the row-reduction weight-gradient products of linear_1 that are not the per-triplet fold
+ * (dGt and the z_other / dist|rank / shared-segment column blocks: csrc/ncx_dwtn.hip) take their fp32 operands as THREE bf16 planes each
+ * (x = x1 + x2 + x3 exactly, by truncation) and run the six products that matter on the bf16 matrix path with fp32 accumulation: what is dropped
+ * is 2^-24 relative, the rounding error of one fp32 operation ("bf16 x 6": fp32-grade, unlike the two-plane "bf16 x 3" form).
+ * Results agree with the fp32 kernels to fp32 rounding, not bitwise (another summation order).  Ignored where the balanced TN launch does not run
+ * (shapes outside dw_tn8_shapes_ok, B > 2048). */
+#define NCX_F_X6       (1u << 7)
 /* (v_emb / q_emb / z_emb lesions replace INPUTS by uniform noise: the host does that before the call) */
 
 typedef struct ncx_dims {

@@ -682,3 +682,45 @@ def test_forward_fold_forms_vs_oracle(K, fold4, H, monkeypatch):
     eight = ops.forward(dims, b, p, ws).cpu()
     assert torch.equal(scores, eight)
 
+
+
+# ---- NCX_F_X6: the balanced TN weight-gradient launch on the bf16 matrix path with three-plane operands (not the default) --------------------
+# The SAME tests at the SAME tolerances ("no tolerance may move for it"); `NCX_X6=1 python -m pytest tests -m gpu` runs the
+# whole suite that way, these wrappers keep the cases that exercise the launch in the default run.
+@pytest.fixture
+def x6(monkeypatch):
+    from neuralcx import _lib, ops
+    monkeypatch.setattr(ops, "EXTRA_FLAGS", _lib.NCX_F_X6)
+
+
+@pytest.mark.parametrize("case", ["all", "no_a_emb", "no_v_mult", "H512_L2", "K48", "dropout"])
+def test_x6_balanced_tn_launch_paths_vs_oracle(case, x6):
+    test_balanced_tn_launch_paths_vs_oracle(case)
+
+
+def test_x6_configs1_full_size_every_logit_and_gradient_vs_oracle(x6):
+    test_configs1_full_size_every_logit_and_gradient_vs_oracle()
+
+
+def test_x6_phased_backward_is_bit_identical(x6):
+    test_phased_backward_is_bit_identical()
+
+
+def test_x6_runs_and_agrees_with_the_fp32_kernels_to_rounding(monkeypatch):
+    """The flag really switches kernels (another summation order: not bitwise equal), and what it computes is the fp32 result to fp32
+    rounding: at configs[1]'s full size every weight-gradient element of linear_1 and the answer embedding within 2e-6 of its tensor's max
+    of the fp32 kernels' (the suite's bound against the oracle is 1e-4 of the max)."""
+    from neuralcx import _lib, ops
+    d = orc.Dims()
+    params, batch = _full_size_case(d, 512, 77)
+    _, _, g32 = run_hip(d, None, params, batch)
+    monkeypatch.setattr(ops, "EXTRA_FLAGS", _lib.NCX_F_X6)
+    _, _, g6 = run_hip(d, None, params, batch)
+    differs = False
+    for k in ("linear_1.weight", "answer_embedding.weight"):
+        a, b = g32[k], g6[k]
+        differs |= not np.array_equal(a, b)
+        assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max(), (k, np.abs(a - b).max(), np.abs(a).max())
+    assert differs
+    for k in ("linear_1.bias", "out.weight"):
+        assert np.array_equal(g32[k], g6[k])

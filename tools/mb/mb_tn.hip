@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <math.h>
+#include <string.h>
 #include <vector>
 #include <algorithm>
 #include <type_traits>
@@ -385,6 +386,464 @@ static float run_d(const TnArgs& a0, int wgs_target, int reps, float* out, bool 
     return med;
 }
 
+
+// ---- the same tile on the bf16 matrix path with fp32-grade operands ("bf16 x 6") ------------------------------------------------------------
+// x = x1 + x2 + x3 EXACTLY (x1 = x & 0xFFFF0000, x2 = (x - x1) & 0xFFFF0000, x3 = x - x1 - x2: three bf16 values by truncation, every
+// residual exact in fp32), products x1.w1 + (x1.w2 + x2.w1) + (x1.w3 + x2.w2 + x3.w1) on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: the
+// dropped terms are 2^-24 relative, the fp32 rounding error itself (tools/exp_bf16x3.py measures it on the oracle: closer to fp64 than fp32 MFMA).
+// 6 MFMAs of 16 cycles replace 8 of 32 per 32-deep block: 2.67 x the rate.  Split at LDS-store time (once per element); LDS holds three bf16
+// planes per operand in the global [k][m] layout, fragments come from ds_read_b64_tr_b16 (hardware transpose), row pitches = 32 mod 256 bytes.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+template <bool SOFTMAX, int ABL = 0, int MASK = 63>
+__global__ __launch_bounds__(512, 1) void k_tn8x6(const TnArgs a) {
+    constexpr int T = 512, BM = 256, BN = 64, BK = 32;
+    constexpr int PA = 544, PB = 160;                          // bytes per k-row of a plane (512 + 32, 128 + 32)
+    constexpr int A_PL = BK * PA, B_PL = BK * PB;              // one plane of one buffer
+    constexpr int BUF = 3 * (A_PL + B_PL);
+    constexpr int NA = 4;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char sm6[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int wm0 = 64 * (wave >> 1), wn0 = 32 * (wave & 1);
+    int id = blockIdx.x, tile, z, nz;
+    if (id < a.n_hi * (a.S + 1)) { tile = id / (a.S + 1); z = id - tile * (a.S + 1); nz = a.S + 1; }
+    else { id -= a.n_hi * (a.S + 1); tile = a.n_hi + id / a.S; z = id - (tile - a.n_hi) * a.S; nz = a.S; }
+    const int n0 = tile * BN;
+    const int total_steps = a.M / BK;
+    const int g0 = (int)((long long)total_steps * z / nz), g1 = (int)((long long)total_steps * (z + 1) / nz);
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int arow = tid >> 6, aq = tid & 63, brow = tid >> 4, bq = tid & 15;
+    const int bcc = min(n0 + 4 * bq, a.N - 4);
+    f32x4 va[2][NA], vb[2];
+    float vl[2];
+    auto issue = [&](auto set_c, int t) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_c)::value;
+        if (ABL == 2) return;
+        const int r0 = min(t, g1 - 1) * BK;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) va[S][i] = *(gf4ptr)((gfptr)a.D + (long long)(r0 + arow + 8 * i) * a.H + 4 * aq);
+        vb[S] = *(gf4ptr)((gfptr)a.X + (long long)(r0 + brow) * a.ldx + bcc);
+        if (SOFTMAX) vl[S] = ((gfptr)a.lse)[r0 + brow];
+    };
+    // x -> three bf16 planes (4 values: one 8-byte store per plane)
+    auto split_store = [&](f32x4 v, unsigned char* base) __attribute__((always_inline)) {
+        unsigned u[4], p1[4], p2[4], p3[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xj = v[j];                   // (a scalar copy: __builtin_bit_cast applied to the vector element v[j] itself reads element 0 -- hipcc 7.2)
+            u[j] = __builtin_bit_cast(unsigned, xj);
+            p1[j] = u[j] & 0xFFFF0000u;
+            const float r1 = xj - __builtin_bit_cast(float, p1[j]);
+            p2[j] = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+            const float r2 = r1 - __builtin_bit_cast(float, p2[j]);
+            p3[j] = __builtin_bit_cast(unsigned, r2) & 0xFFFF0000u;
+        }
+        const u32x2 w1 = {(p1[0] >> 16) | p1[1], (p1[2] >> 16) | p1[3]};
+        const u32x2 w2 = {(p2[0] >> 16) | p2[1], (p2[2] >> 16) | p2[3]};
+        const u32x2 w3 = {(p3[0] >> 16) | p3[1], (p3[2] >> 16) | p3[3]};
+        *(u32x2*)(base) = w1; *(u32x2*)(base + (A_PL + B_PL)) = w2; *(u32x2*)(base + 2 * (A_PL + B_PL)) = w3;
+    };
+    // buffer b: [plane p][A rows | B rows]: plane p at b * BUF + p * (A_PL + B_PL); A part first
+    auto stash = [&](auto set_c, int buf, int h0, int h1) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_c)::value;
+        if (ABL == 3) return;
+        unsigned char* const base = sm6 + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (i < h0 || i >= h1) continue;
+            split_store(va[S][i], base + (arow + 8 * i) * PA + aq * 8);
+        }
+        if (NA >= h0 && NA < h1) {
+            f32x4 v = vb[S];
+            if (SOFTMAX) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[j], 1.44269504088896341f, -vl[S]));
+            }
+            split_store(v, base + A_PL + brow * PB + bq * 8);
+        }
+    };
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+    const int tq = li >> 2, tp = li & 3;
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        if (ABL == 1) return;
+        const unsigned char* const base = sm6 + buf * BUF;
+        bf16x8 af[3][4], bf[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const unsigned char* ta = base + p * (A_PL + B_PL) + (4 * lk + tq) * PA + (wm0 + 4 * tp) * 2;
+            const unsigned char* tb = base + p * (A_PL + B_PL) + A_PL + (4 * lk + tq) * PB + (wn0 + 4 * tp) * 2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ta + i * 32));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ta + i * 32 + 16 * PA));
+                af[p][i] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tb + j * 32));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tb + j * 32 + 16 * PB));
+                bf[p][j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+        }
+        // smallest terms first: (x1 w3 + x2 w2 + x3 w1), (x1 w2 + x2 w1), x1 w1
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f32x4 c = acc[i][j];
+                if (MASK & 1)  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[2][j], c, 0, 0, 0);
+                if (MASK & 2)  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i], bf[1][j], c, 0, 0, 0);
+                if (MASK & 4)  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2][i], bf[0][j], c, 0, 0, 0);
+                if (MASK & 8)  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[1][j], c, 0, 0, 0);
+                if (MASK & 16) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1][i], bf[0][j], c, 0, 0, 0);
+                if (MASK & 32) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i], bf[0][j], c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+    };
+    typedef IntC<0> S0; typedef IntC<1> S1;
+    issue(S0{}, g0);
+    issue(S1{}, g0 + 1);
+    stash(S0{}, 0, 0, NA + 1);
+    issue(S0{}, g0 + 2);
+    __syncthreads();
+    auto step = [&](auto par_c, int t) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_c)::value;
+        typedef IntC<PAR ^ 1> SS;
+        stash(SS{}, PAR ^ 1, 0, NA + 1);
+        issue(SS{}, t + 3);
+        compute(PAR);
+        __syncthreads();
+    };
+    int t = g0;
+    for (; t + 1 < g1; t += 2) { step(IntC<0>{}, t); step(IntC<1>{}, t + 1); }
+    if (t < g1) step(IntC<0>{}, t);
+    float* const slot = a.slab + (long long)blockIdx.x * (BM * BN);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int row = wm0 + 16 * i + 4 * lk + rg;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) slot[row * BN + wn0 + 16 * j + li] = acc[i][j][rg];
+        }
+}
+
+
+// The same arithmetic, pipelined like k_tn8: a k-step is four sub-steps (one per 16-row block column i of the wave's A side: 12 MFMAs), the
+// fragment reads of sub-step i + 1, the split + LDS stores of the next tile (two quads per sub-step) and the global loads of the tile after it
+// are pinned between the MFMAs of sub-step i; the last sub-step's MFMAs run after the barrier, over the first reads of the next buffer.
+template <bool SOFTMAX, int VARIANT = 0>
+__global__ __launch_bounds__(512, 1) void k_tn8x6p(const TnArgs a) {
+    constexpr int T = 512, BM = 256, BN = 64, BK = 32;
+    constexpr int PA = 544, PB = 160;
+    constexpr int A_PL = BK * PA, B_PL = BK * PB, PL = A_PL + B_PL;
+    constexpr int BUF = 3 * PL;
+    constexpr int NA = 4;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char sm6[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int wm0 = 64 * (wave >> 1), wn0 = 32 * (wave & 1);
+    int id = blockIdx.x, tile, z, nz;
+    if (id < a.n_hi * (a.S + 1)) { tile = id / (a.S + 1); z = id - tile * (a.S + 1); nz = a.S + 1; }
+    else { id -= a.n_hi * (a.S + 1); tile = a.n_hi + id / a.S; z = id - (tile - a.n_hi) * a.S; nz = a.S; }
+    unsigned long long* const stamps = a.stamps ? a.stamps + (size_t)blockIdx.x * 8 : nullptr;
+    if (stamps && tid == 0) { stamps[0] = __builtin_readcyclecounter(); stamps[6] = __builtin_amdgcn_s_memrealtime(); }
+    const int n0 = tile * BN;
+    const int total_steps = a.M / BK;
+    const int g0 = (int)((long long)total_steps * z / nz), g1 = (int)((long long)total_steps * (z + 1) / nz);
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int arow = tid >> 6, aq = tid & 63, brow = tid >> 4, bq = tid & 15;
+    const int bcc = min(n0 + 4 * bq, a.N - 4);
+    constexpr int NSET = (VARIANT >= 20 && VARIANT < 30) ? 3 : 2;       // register sets of global loads in flight
+    f32x4 va[NSET][NA], vb[NSET];
+    float vl[NSET];
+    auto issue_part = [&](auto set_c, int t, int h0, int h1) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_c)::value;
+        if (VARIANT == 12) return;
+        const int r0 = VARIANT == 15 ? (t & 3) * BK : min(t, g1 - 1) * BK;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) { if (i < h0 || i >= h1) continue; va[S][i] = *(gf4ptr)((gfptr)a.D + (long long)(r0 + arow + 8 * i) * a.H + 4 * aq); }
+        if (NA >= h0 && NA < h1) {
+            vb[S] = *(gf4ptr)((gfptr)a.X + (long long)(r0 + brow) * a.ldx + bcc);
+            if (SOFTMAX) vl[S] = ((gfptr)a.lse)[r0 + brow];
+        }
+    };
+    auto issue = [&](auto set_c, int t) __attribute__((always_inline)) { issue_part(set_c, t, 0, NA + 1); };
+    float dummy = 0.f; const float cst = (float)a.M * 0.37f;
+    auto split_store = [&](f32x4 v, unsigned char* base) __attribute__((always_inline)) {
+        if (VARIANT == 13) return;
+        if (VARIANT == 16) {
+            dummy += (float)v[0] + (float)v[3];
+            v = f32x4{cst, cst * 3.f, cst * 5.f, cst * 7.f};
+        }
+        if (VARIANT == 10) {
+            const u32x2 w1 = {__builtin_bit_cast(unsigned, (float)v[0]), __builtin_bit_cast(unsigned, (float)v[1])}, w2 = {__builtin_bit_cast(unsigned, (float)v[2]), __builtin_bit_cast(unsigned, (float)v[3])};
+            *(u32x2*)(base) = w1; *(u32x2*)(base + PL) = w2; *(u32x2*)(base + 2 * PL) = w1;
+            return;
+        }
+        unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xj = v[j];
+            p1[j] = __builtin_bit_cast(unsigned, xj) & 0xFFFF0000u;
+            const float r1 = xj - __builtin_bit_cast(float, p1[j]);
+            p2[j] = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+            const float r2 = r1 - __builtin_bit_cast(float, p2[j]);
+            p3[j] = __builtin_bit_cast(unsigned, r2);            // (at most 8 significant bits are left: the high half is all of it)
+        }
+        // v_perm_b32: the high halves of two dwords -> one dword (element j in the low half)
+        const u32x2 w1 = {__builtin_amdgcn_perm(p1[1], p1[0], 0x07060302u), __builtin_amdgcn_perm(p1[3], p1[2], 0x07060302u)};
+        const u32x2 w2 = {__builtin_amdgcn_perm(p2[1], p2[0], 0x07060302u), __builtin_amdgcn_perm(p2[3], p2[2], 0x07060302u)};
+        const u32x2 w3 = {__builtin_amdgcn_perm(p3[1], p3[0], 0x07060302u), __builtin_amdgcn_perm(p3[3], p3[2], 0x07060302u)};
+        *(u32x2*)(base) = w1; *(u32x2*)(base + PL) = w2; *(u32x2*)(base + 2 * PL) = w3;
+    };
+    auto stash = [&](auto set_c, int buf, int h0, int h1) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_c)::value;
+        unsigned char* const base = sm6 + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (i < h0 || i >= h1) continue;
+            split_store(va[S][i], base + (arow + 8 * i) * PA + aq * 8);
+        }
+        if (NA >= h0 && NA < h1) {
+            f32x4 v = vb[S];
+            if (SOFTMAX) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float xj = v[j]; v[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(xj, 1.44269504088896341f, -vl[S])); }
+            }
+            split_store(v, base + A_PL + brow * PB + bq * 8);
+        }
+    };
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+    const int tq = li >> 2, tp = li & 3;
+    const int offA = (4 * lk + tq) * PA + (wm0 + 4 * tp) * 2, offB = A_PL + (4 * lk + tq) * PB + (wn0 + 4 * tp) * 2;
+    auto read_a = [&](int buf, int i, bf16x8 (&af)[3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            if (VARIANT == 14 && p > 0) { af[p] = af[0]; continue; }
+            const unsigned char* ta = sm6 + buf * BUF + p * PL + offA + i * 32;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ta));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ta + 16 * PA));
+            af[p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+    };
+    auto read_b = [&](int buf, bf16x8 (&bf)[3][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (VARIANT == 14 && p > 0) { bf[p][j] = bf[0][j]; continue; }
+                const unsigned char* tb = sm6 + buf * BUF + p * PL + offB + j * 32;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tb));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tb + 16 * PB));
+                bf[p][j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+    };
+    // 12 MFMAs of block row i: the two column blocks alternate (a dependent MFMA is two issues away); small terms first
+    auto mfma12 = [&](const bf16x8 (&af)[3], const bf16x8 (&bf)[3][2], f32x4 (&c)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[2][j], c[j], 0, 0, 0);
+        if (VARIANT == 11) { c[0][0] += (float)af[1][0] + (float)af[2][0] + (float)bf[1][0][0] + (float)bf[1][1][0] + (float)bf[0][0][0] + (float)bf[0][1][0]; return; }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[1][j], c[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[0][j], c[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[1][j], c[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[0][j], c[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[0][j], c[j], 0, 0, 0);
+    };
+    typedef IntC<0> S0; typedef IntC<1> S1;
+    bf16x8 afA[3], afB[3], bfr[2][3][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        afB[p] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bfr[1][p][j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    auto pin = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, VARIANT == 1 ? 3 : 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if constexpr (NSET == 3) {
+        // three sets: tile t lives in set (t - g0) % 3; step n stashes tile n + 1 and re-issues set n % 3 (stashed one step ago) FIRST: a load has two k-steps to land
+        issue(IntC<0>{}, g0); issue(IntC<1>{}, g0 + 1); issue(IntC<2>{}, g0 + 2);
+        stash(IntC<0>{}, 0, 0, NA + 1);
+        __syncthreads();
+        auto step3 = [&](auto par_c, auto ns_c, int t) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_c)::value, NS = decltype(ns_c)::value;
+            typedef IntC<(NS + 1) % 3> SS;
+            read_b(PAR, bfr[PAR]);
+            read_a(PAR, 0, afA);
+            issue(IntC<NS>{}, t + 3);
+            mfma12(afB, bfr[PAR ^ 1], acc[3]);
+#pragma unroll
+            for (int q = 0; q < 12; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(PAR, 1, afB);
+            stash(SS{}, PAR ^ 1, 0, 2);
+            mfma12(afA, bfr[PAR], acc[0]);
+            pin();
+            read_a(PAR, 2, afA);
+            stash(SS{}, PAR ^ 1, 2, 4);
+            mfma12(afB, bfr[PAR], acc[1]);
+            pin();
+            read_a(PAR, 3, afB);
+            stash(SS{}, PAR ^ 1, 4, 5);
+            mfma12(afA, bfr[PAR], acc[2]);
+            pin();
+            __syncthreads();
+        };
+        int t = g0;
+        for (; t + 5 < g1; t += 6) {
+            step3(IntC<0>{}, IntC<0>{}, t); step3(IntC<1>{}, IntC<1>{}, t + 1); step3(IntC<0>{}, IntC<2>{}, t + 2);
+            step3(IntC<1>{}, IntC<0>{}, t + 3); step3(IntC<0>{}, IntC<1>{}, t + 4); step3(IntC<1>{}, IntC<2>{}, t + 5);
+        }
+        // (the microbenchmark's chunks are multiples of 6 k-steps; anything else would need the tail here)
+        mfma12(afB, bfr[1], acc[3]);
+    } else {
+    issue(S0{}, g0);
+    issue(S1{}, g0 + 1);
+    stash(S0{}, 0, 0, NA + 1);
+    issue(S0{}, g0 + 2);
+    __syncthreads();
+    // VARIANT 0 / 1x: the loads of tile t + 3 are spread over the step (one every four MFMAs): a burst of six per wave from eight waves
+    // at one program point queues on the CU's address unit (16 cycles per 1 KB load) and stalls the in-order waves behind it
+    auto pin_spread = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            if (q % 4 == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto stash_b = [&](auto set_c, int buf) __attribute__((always_inline)) { stash(set_c, buf, NA, NA + 1); };
+    auto step = [&](auto par_c, int t) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_c)::value;
+        typedef IntC<PAR ^ 1> SS;
+        read_b(PAR, bfr[PAR]);
+        read_a(PAR, 0, afA);
+        mfma12(afB, bfr[PAR ^ 1], acc[3]);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        if (VARIANT == 1) {          // the burst form (all six loads in the last sub-step)
+            read_a(PAR, 1, afB); stash(SS{}, PAR ^ 1, 0, 2); mfma12(afA, bfr[PAR], acc[0]); pin();
+            read_a(PAR, 2, afA); stash(SS{}, PAR ^ 1, 2, 4); mfma12(afB, bfr[PAR], acc[1]); pin();
+            read_a(PAR, 3, afB); stash(SS{}, PAR ^ 1, 4, 5); issue(SS{}, t + 3); mfma12(afA, bfr[PAR], acc[2]); pin();
+        } else {
+            read_a(PAR, 1, afB); stash_b(SS{}, PAR ^ 1); stash(SS{}, PAR ^ 1, 0, 1); mfma12(afA, bfr[PAR], acc[0]); pin_spread();
+            read_a(PAR, 2, afA); stash(SS{}, PAR ^ 1, 1, 3); issue_part(SS{}, t + 3, NA, NA + 1); issue_part(SS{}, t + 3, 0, 1); mfma12(afB, bfr[PAR], acc[1]); pin_spread();
+            read_a(PAR, 3, afB); stash(SS{}, PAR ^ 1, 3, 4); issue_part(SS{}, t + 3, 1, 4); mfma12(afA, bfr[PAR], acc[2]); pin_spread();
+        }
+        __syncthreads();
+    };
+    int t = g0;
+    for (; t + 1 < g1; t += 2) { step(IntC<0>{}, t); step(IntC<1>{}, t + 1); }
+    if (t < g1) { step(IntC<0>{}, t); mfma12(afB, bfr[0], acc[3]); }
+    else mfma12(afB, bfr[1], acc[3]);
+    }
+    if (VARIANT == 16) acc[0][0][0] += dummy;
+    if (stamps && tid == 0) { stamps[1] = __builtin_readcyclecounter(); stamps[2] = stamps[1]; stamps[7] = __builtin_amdgcn_s_memrealtime(); }
+    float* const slot = a.slab + (long long)blockIdx.x * (BM * BN);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int row = wm0 + 16 * i + 4 * lk + rg;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) slot[row * BN + wn0 + 16 * j + li] = acc[i][j][rg];
+        }
+}
+
+template <bool SOFTMAX, int VARIANT>
+static float run_x6p(const TnArgs& a0, int wgs_target, int reps, float* out, bool verbose, const char* name) {
+    constexpr int BN = 64;
+    TnArgs a = a0;
+    a.tiles_n = (a.N + BN - 1) / BN;
+    a.S = wgs_target / a.tiles_n; if (a.S < 1) a.S = 1;
+    a.n_hi = wgs_target - a.S * a.tiles_n; if (a.n_hi < 0 || a.n_hi > a.tiles_n) a.n_hi = 0;
+    const int wgs = a.S * a.tiles_n + a.n_hi;
+    const int lds = 2 * 3 * 32 * (544 + 160);
+    CHECK(hipFuncSetAttribute((const void*)k_tn8x6p<SOFTMAX, VARIANT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CHECK(hipMalloc(&a.slab, (size_t)wgs * 256 * BN * 4));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_tn8x6p<SOFTMAX, VARIANT>), dim3(wgs), dim3(512), lds, 0, a);
+    CHECK(hipDeviceSynchronize());
+    std::vector<float> ts;
+    for (int i = 0; i < reps; ++i) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k_tn8x6p<SOFTMAX, VARIANT>), dim3(wgs), dim3(512), lds, 0, a);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms);
+    }
+    std::sort(ts.begin(), ts.end());
+    const float med = ts[ts.size() / 2];
+    if (out) {
+        hipLaunchKernelGGL((k_reduce<BN>), dim3((unsigned)(((long long)256 * a.N + 255) / 256)), dim3(256), 0, 0, a.slab, 256, a.N, a.S, a.n_hi, out);
+        CHECK(hipDeviceSynchronize());
+    }
+    const double gf = 2.0 * a.M * 256.0 * a.N / 1e9;
+    if (verbose) printf("%-34s wgs %3d (S %d)  lds %6d  min %.1f med %.1f us  %.1f TFLOP/s fp32-equivalent (%.3f of the 157.3 fp32-MFMA peak)\n", name, wgs, a.S, lds,
+                        ts[0] * 1e3, med * 1e3, gf / med, gf / med / 157.3);
+    CHECK(hipFree(a.slab));
+    return med;
+}
+
+template <bool SOFTMAX, int ABL, int MASK = 63>
+static float run_x6(const TnArgs& a0, int wgs_target, int reps, float* out, bool verbose, const char* name) {
+    constexpr int BN = 64;
+    TnArgs a = a0;
+    a.tiles_n = (a.N + BN - 1) / BN;
+    a.S = wgs_target / a.tiles_n; if (a.S < 1) a.S = 1;
+    a.n_hi = wgs_target - a.S * a.tiles_n; if (a.n_hi < 0 || a.n_hi > a.tiles_n) a.n_hi = 0;
+    const int wgs = a.S * a.tiles_n + a.n_hi;
+    const int lds = 2 * 3 * 32 * (544 + 160);
+    CHECK(hipFuncSetAttribute((const void*)k_tn8x6<SOFTMAX, ABL, MASK>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CHECK(hipMalloc(&a.slab, (size_t)wgs * 256 * BN * 4));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_tn8x6<SOFTMAX, ABL, MASK>), dim3(wgs), dim3(512), lds, 0, a);
+    CHECK(hipDeviceSynchronize());
+    std::vector<float> ts;
+    for (int i = 0; i < reps; ++i) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k_tn8x6<SOFTMAX, ABL, MASK>), dim3(wgs), dim3(512), lds, 0, a);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms);
+    }
+    std::sort(ts.begin(), ts.end());
+    const float med = ts[ts.size() / 2];
+    if (out) {
+        hipLaunchKernelGGL((k_reduce<BN>), dim3((unsigned)(((long long)256 * a.N + 255) / 256)), dim3(256), 0, 0, a.slab, 256, a.N, a.S, a.n_hi, out);
+        CHECK(hipDeviceSynchronize());
+    }
+    const double gf = 2.0 * a.M * 256.0 * a.N / 1e9;
+    if (verbose) printf("%-34s wgs %3d (S %d)  lds %6d  min %.1f med %.1f us  %.1f TFLOP/s fp32-equivalent (%.3f of the 157.3 fp32-MFMA peak)\n", name, wgs, a.S, lds,
+                        ts[0] * 1e3, med * 1e3, gf / med, gf / med / 157.3);
+    CHECK(hipFree(a.slab));
+    return med;
+}
+
 template <int BN, bool SOFTMAX, int ABL>
 static float run(const TnArgs& a0, int wgs_target, int reps, float* out, bool verbose, const char* name) {
     TnArgs a = a0;
@@ -420,7 +879,74 @@ static float run(const TnArgs& a0, int wgs_target, int reps, float* out, bool ve
     return med;
 }
 
+
+// ---- diagnostic: what the split stores and the transposed reads of k_tn8x6 really see ------------------------------------------------------
+__global__ void k_dbg_split(const float* x /*[32][64]*/, unsigned short* planes /*[3][32][64]*/, unsigned short* frag /*[3][64 lanes][8]*/) {
+    constexpr int PB = 160, B_PL = 32 * PB;
+    __shared__ __attribute__((aligned(1024))) unsigned char sm[3 * B_PL];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    const int brow = tid >> 4, bq = tid & 15;                // 512 threads: 32 rows x 16 quads
+    const f32x4 v = *(const f32x4*)(x + brow * 64 + 4 * bq);
+    unsigned p1[4], p2[4], p3[4];
+    for (int j = 0; j < 4; ++j) {
+        const float xj = v[j];
+        const unsigned u = __builtin_bit_cast(unsigned, xj);
+        p1[j] = u & 0xFFFF0000u;
+        const float r1 = xj - __builtin_bit_cast(float, p1[j]);
+        p2[j] = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+        const float r2 = r1 - __builtin_bit_cast(float, p2[j]);
+        p3[j] = __builtin_bit_cast(unsigned, r2) & 0xFFFF0000u;
+    }
+    unsigned char* base = sm + brow * PB + bq * 8;
+    *(u32x2*)(base) = u32x2{(p1[0] >> 16) | p1[1], (p1[2] >> 16) | p1[3]};
+    *(u32x2*)(base + B_PL) = u32x2{(p2[0] >> 16) | p2[1], (p2[2] >> 16) | p2[3]};
+    *(u32x2*)(base + 2 * B_PL) = u32x2{(p3[0] >> 16) | p3[1], (p3[2] >> 16) | p3[3]};
+    __syncthreads();
+    for (int i = tid; i < 3 * 32 * 64; i += 512) {
+        const int p = i / (32 * 64), r = (i / 64) % 32, c = i % 64;
+        planes[i] = *(const unsigned short*)(sm + p * B_PL + r * PB + c * 2);
+    }
+    if (tid < 64) {
+        typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+        const int tq = li >> 2, tp = li & 3;
+        for (int p = 0; p < 3; ++p) {
+            const unsigned char* tb = sm + p * B_PL + (4 * lk + tq) * PB + (0 + 4 * tp) * 2;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tb));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tb + 16 * PB));
+            for (int j = 0; j < 4; ++j) { frag[(p * 64 + lane) * 8 + j] = (unsigned short)lo[j]; frag[(p * 64 + lane) * 8 + 4 + j] = (unsigned short)hi[j]; }
+        }
+    }
+}
+static void debug_split() {
+    std::vector<float> hx(32 * 64);
+    for (int i = 0; i < 32 * 64; ++i) hx[i] = (float)(i / 64) + (float)(i % 64) / 256.f + 1.0f / 3.0f;       // row r, column c encoded in the value
+    float* dx; unsigned short *dp, *df;
+    CHECK(hipMalloc(&dx, hx.size() * 4)); CHECK(hipMalloc(&dp, 3 * 32 * 64 * 2)); CHECK(hipMalloc(&df, 3 * 64 * 8 * 2));
+    CHECK(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_dbg_split, dim3(1), dim3(512), 0, 0, dx, dp, df);
+    CHECK(hipDeviceSynchronize());
+    std::vector<unsigned short> hp(3 * 32 * 64), hf(3 * 64 * 8);
+    CHECK(hipMemcpy(hp.data(), dp, hp.size() * 2, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(hf.data(), df, hf.size() * 2, hipMemcpyDeviceToHost));
+    auto b2f = [](unsigned short b) { unsigned u = (unsigned)b << 16; float f; memcpy(&f, &u, 4); return f; };
+    int bad = 0;
+    for (int r = 0; r < 32; ++r) for (int c = 0; c < 64; ++c) {
+        const float x = hx[r * 64 + c];
+        const double sum = (double)b2f(hp[r * 64 + c]) + b2f(hp[2048 + r * 64 + c]) + b2f(hp[4096 + r * 64 + c]);
+        if (fabs(sum - x) > 1e-7 * fabs(x) || fabs(b2f(hp[2048 + r * 64 + c])) > 0.01 * fabs(x)) { if (bad < 4) printf("   plane mismatch r %d c %d: x %.8f planes %.8f %.3e %.3e\n", r, c, x, b2f(hp[r * 64 + c]), b2f(hp[2048 + r * 64 + c]), b2f(hp[4096 + r * 64 + c])); ++bad; }
+    }
+    printf("dbg split: %d of 2048 elements whose three planes do not sum to x (or whose middle plane is not small)\n", bad);
+    // fragments of plane 0: which (row, column) does lane l, element e hold?  value = r + c / 256 + 1/3 (truncated to bf16: r exact for r < 128)
+    for (int l = 0; l < 64; l += 9) {
+        printf("   lane %2d (li %2d lk %d): ", l, l & 15, l >> 4);
+        for (int e = 0; e < 8; ++e) printf("%.3f ", b2f(hf[l * 8 + e]));
+        printf(" | mid plane: ");
+        for (int e = 0; e < 8; ++e) printf("%.1e ", b2f(hf[(64 + l) * 8 + e]));
+        printf("\n");
+    }
+}
+
 int main(int argc, char** argv) {
+    if (getenv("MB_TN_DEBUG_SPLIT")) debug_split();
     const int M = argc > 1 ? atoi(argv[1]) : 12288, N = argc > 2 ? atoi(argv[2]) : 2000, reps = argc > 3 ? atoi(argv[3]) : 20;
     const int H = 256;
     std::vector<float> hD((size_t)M * H), hX((size_t)M * N), hl(M);
@@ -449,7 +975,8 @@ int main(int argc, char** argv) {
             for (int r = 0; r < M; ++r) ref += (double)hD[(size_t)r * H + h] * exp2((double)hX[(size_t)r * N + n] * 1.4426950408889634 - (double)hl[r]);
             worst = std::max(worst, fabs(ref - ho[(size_t)h * N + n])); mag = std::max(mag, fabs(ref));
         }
-        printf("   check %-24s max |err| %.3e (max |ref| %.3e)\n", name, worst, mag);
+        double omax = 0; for (size_t q = 0; q < ho.size(); q += 97) omax = std::max(omax, (double)fabs(ho[q]));
+        printf("   check %-24s max |err| %.3e (max |ref| %.3e; max |out| sampled %.3e)\n", name, worst, mag, omax);
     };
     // warm the chip
     for (int i = 0; i < 30; ++i) run<64, true, 0>(a, 256, 3, nullptr, false, "");
@@ -463,24 +990,50 @@ int main(int argc, char** argv) {
     run<128, true, 2>(a, 256, reps, nullptr, true, "256x128 ABL no global loads");
     run<128, true, 3>(a, 256, reps, nullptr, true, "256x128 ABL no LDS stores");
     run<64, false, 0>(a, 256, reps, nullptr, true, "256x64  plain operand");
+    run_x6<true, 0>(a, 256, reps, dout, true, "256x64  bf16 x 6 (fp32-grade)"); check("256x64 bf16x6");
+    run_x6p<true, 0>(a, 256, reps, dout, true, "256x64  bf16 x 6 pipelined"); check("256x64 bf16x6 pipelined");
+    run_x6p<true, 1>(a, 256, reps, dout, true, "256x64  bf16 x 6 pipelined, load burst"); check("256x64 bf16x6 pipelined v1");
+    run_x6p<false, 0>(a, 256, reps, nullptr, true, "256x64  bf16 x 6 pipelined plain");
+    run_x6p<true, 20>(a, 256, reps, dout, true, "256x64  bf16 x 6, 3 load sets"); check("256x64 bf16x6 3 sets");
+    run_x6p<true, 15>(a, 256, reps, nullptr, true, "   x6p ABL loads of the same 4 tiles");
+    run_x6p<true, 16>(a, 256, reps, nullptr, true, "   x6p ABL stores do not depend on loads");
+    run_x6p<true, 10>(a, 256, reps, nullptr, true, "   x6p ABL no split arithmetic");
+    run_x6p<true, 11>(a, 256, reps, nullptr, true, "   x6p ABL 2 of 12 MFMAs");
+    run_x6p<true, 12>(a, 256, reps, nullptr, true, "   x6p ABL no global loads");
+    run_x6p<true, 13>(a, 256, reps, nullptr, true, "   x6p ABL no LDS stores");
+    run_x6p<true, 14>(a, 256, reps, nullptr, true, "   x6p ABL 1/3 of the fragment reads");
+    run_x6<true, 0, 32>(a, 256, 2, dout, false, ""); check("x6 terms: hi.hi");
+    run_x6<true, 0, 32 + 8>(a, 256, 2, dout, false, ""); check("x6 terms: + hi.mid");
+    run_x6<true, 0, 32 + 16>(a, 256, 2, dout, false, ""); check("x6 terms: + mid.hi");
+    run_x6<true, 0, 32 + 8 + 16>(a, 256, 2, dout, false, ""); check("x6 terms: + hi.mid + mid.hi");
+    run_x6<true, 0, 8>(a, 256, 2, dout, false, ""); check("x6 terms: hi.mid ALONE");
+    run_x6<true, 0, 16>(a, 256, 2, dout, false, ""); check("x6 terms: mid.hi ALONE");
+    run_x6<true, 1>(a, 256, reps, nullptr, true, "256x64  bf16 x 6 ABL no mfma/reads");
+    run_x6<true, 2>(a, 256, reps, nullptr, true, "256x64  bf16 x 6 ABL no global loads");
+    run_x6<true, 3>(a, 256, reps, nullptr, true, "256x64  bf16 x 6 ABL no LDS stores");
     run_d<true, 0, true>(a, 256, reps, dout, true, "256x64  LDS-DMA (nt X)"); check("256x64 dma");
     run_d<true, 0, false>(a, 256, reps, nullptr, true, "256x64  LDS-DMA (no nt hint)");
     run_d<true, 1, true>(a, 256, reps, nullptr, true, "256x64  LDS-DMA ABL no mfma");
     run_d<true, 2, true>(a, 256, reps, nullptr, true, "256x64  LDS-DMA ABL no loads");
     run_d<false, 0, true>(a, 256, reps, nullptr, true, "256x64  LDS-DMA plain operand");
     // stamps: per-workgroup loop / epilogue cycles and the held clock
-    {
+    auto stamped = [&](const char* name, auto runner) {
         unsigned long long* st; CHECK(hipMalloc(&st, 256 * 8 * 8)); CHECK(hipMemset(st, 0, 256 * 8 * 8));
         TnArgs b = a; b.stamps = st;
-        run<64, true, 0>(b, 256, 3, nullptr, false, "");
+        runner(b);
         std::vector<unsigned long long> hs(256 * 8);
         CHECK(hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost));
         std::vector<double> loop, epi, mhz, dur;
         for (int w = 0; w < 256; ++w) { const auto* s = &hs[w * 8]; if (s[7] > s[6]) { loop.push_back((double)(s[1] - s[0])); epi.push_back((double)(s[2] - s[1])); mhz.push_back((double)(s[2] - s[0]) / (s[7] - s[6]) * 100.0); dur.push_back((s[7] - s[6]) / 100.0); } }
         auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
         auto mx = [](const std::vector<double>& v) { double m = 0; for (double x : v) m = std::max(m, x); return m; };
-        printf("stamps 256x64: loop cycles med %.0f max %.0f | epilogue med %.0f | sclk med %.0f MHz | workgroup us med %.1f max %.1f\n", med(loop), mx(loop), med(epi), med(mhz), med(dur), mx(dur));
+        printf("stamps %-28s loop cycles med %.0f max %.0f | epilogue med %.0f | sclk med %.0f MHz | workgroup us med %.1f max %.1f\n", name, med(loop), mx(loop), med(epi), med(mhz), med(dur), mx(dur));
         CHECK(hipFree(st));
-    }
+    };
+    stamped("256x64 fp32", [&](const TnArgs& b) { run<64, true, 0>(b, 256, 3, nullptr, false, ""); });
+    stamped("256x64 bf16x6 pipelined", [&](const TnArgs& b) { run_x6p<true, 0>(b, 256, 3, nullptr, false, ""); });
+    stamped("256x64 bf16x6 no loads", [&](const TnArgs& b) { run_x6p<true, 12>(b, 256, 3, nullptr, false, ""); });
+    stamped("256x64 bf16x6 no split", [&](const TnArgs& b) { run_x6p<true, 10>(b, 256, 3, nullptr, false, ""); });
+    stamped("256x64 bf16x6 R + M only", [&](const TnArgs& b) { run_x6p<true, 13>(b, 256, 3, nullptr, false, ""); });
     return 0;
 }

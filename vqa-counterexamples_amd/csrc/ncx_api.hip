@@ -1053,7 +1053,7 @@ static int check_dims(const ncx_dims* d) {
     if ((long long)d->B * d->K > (1ll << 30) / 4 || d->B > NCX_SCATTER_MAX_B) return NCX_E_DIMS;
     if (d->dv < 4 || d->dq < 4 || d->dz < 4 || d->da < 4 || d->A < 4 || d->H < 4 || d->K < 3) return NCX_E_DIMS;   // 16-byte windows
     if (d->drop_p < 0.f || d->drop_p >= 1.f) return NCX_E_DIMS;
-    if (d->flags & ~(NCX_F_ALL | NCX_F_BF16 | NCX_F_REUSE_GT | NCX_F_FUSED_TAIL)) return NCX_E_FLAGS;
+    if (d->flags & ~(NCX_F_ALL | NCX_F_BF16 | NCX_F_REUSE_GT | NCX_F_FUSED_TAIL | NCX_F_X6)) return NCX_E_FLAGS;
     if ((d->flags & NCX_F_BF16) && (d->flags & NCX_F_ALL) != NCX_F_ALL) return NCX_E_FLAGS;    // bf16 variant: no lesions
     return NCX_OK;
 }

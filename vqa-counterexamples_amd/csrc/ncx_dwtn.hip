@@ -68,6 +68,44 @@ struct Tn8Seg {
 };
 static_assert(sizeof(Tn8Seg) == TN8_SEG_WORDS * 4, "segment record");
 
+// this workgroup's pieces (thread 0): the aligned chunk, then its range of the rest sequence
+__device__ __forceinline__ void tn8_pieces(const Tn8Args& a, int w, Tn8Seg* segs, int* nseg_out, int* vtot_out) {
+    constexpr int BM = TN8_BM, BN = TN8_BN, BK = TN8_BK;
+    int n = 0, v = 0;
+    auto put = [&](int prob, int tile, int t0, int t1, int slot) {
+        const Tn8Prob& p = a.p[prob];
+        const int tm = tile % a.tiles_m, tn = tile / a.tiles_m;
+        Tn8Seg sg;
+        sg.a_ptr = (unsigned long long)(uintptr_t)(p.A + (long long)tm * BM);
+        sg.x_ptr = (unsigned long long)(uintptr_t)p.X;
+        sg.l_ptr = (unsigned long long)(uintptr_t)(p.lse ? p.lse : p.A);
+        sg.ldx = (int)p.ldx; sg.soft = p.lse ? 1 : 0; sg.gsel = p.gsel;
+        sg.n0 = tn * BN; sg.ncl = p.N - 4; sg.t0 = t0; sg.vbeg = v; sg.vend = v + (t1 - t0); sg.slot = slot; sg.rv = p.rows_valid > 0 ? p.rows_valid : p.rows;
+        if (n < TN8_MAX_SEG) segs[n++] = sg;
+        v += t1 - t0;
+    };
+    if (a.do_al && w < a.al_wgs) {
+        const int tile = w / a.S, z = w - tile * a.S;
+        const int steps = a.p[0].rows / BK;
+        const int g0 = (int)((long long)steps * z / a.S), g1 = (int)((long long)steps * (z + 1) / a.S);
+        if (g1 > g0) put(0, tile, g0, g1, w);
+    }
+    if (a.do_rest) {
+        long long g = (long long)w * a.R;
+        const long long gend = min(g + a.R, (long long)a.rest_pre[a.np]);
+        int pr = a.n_al;
+        while (g < gend) {
+            while (pr + 1 < a.np && g >= a.rest_pre[pr + 1]) ++pr;
+            const int local = (int)(g - a.rest_pre[pr]);
+            const int tile = local / a.rest_steps[pr], t0 = local - tile * a.rest_steps[pr];
+            const int t1 = (int)min((long long)a.rest_steps[pr], t0 + (gend - g));
+            put(pr, tile, t0, t1, a.al_wgs + a.rest_tile0[pr] + tile + w);
+            g += t1 - t0;
+        }
+    }
+    *nseg_out = n; *vtot_out = v;
+}
+
 __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
     constexpr int T = TN8_T, BM = TN8_BM, BN = TN8_BN, BK = TN8_BK, PA = TN8_PA, PB = TN8_PB;
     constexpr int WM = 4, WN = 2, NA = 4, NMF = 2 * WM * WN;
@@ -81,42 +119,7 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
     const int wm0 = 64 * (wave >> 1), wn0 = 32 * (wave & 1);
     const int w = blockIdx.x;
 
-    // ---- this workgroup's pieces ---------------------------------------------------------------------------------------------------
-    if (tid == 0) {
-        int n = 0, v = 0;
-        auto put = [&](int prob, int tile, int t0, int t1, int slot) {
-            const Tn8Prob& p = a.p[prob];
-            const int tm = tile % a.tiles_m, tn = tile / a.tiles_m;
-            Tn8Seg sg;
-            sg.a_ptr = (unsigned long long)(uintptr_t)(p.A + (long long)tm * BM);
-            sg.x_ptr = (unsigned long long)(uintptr_t)p.X;
-            sg.l_ptr = (unsigned long long)(uintptr_t)(p.lse ? p.lse : p.A);
-            sg.ldx = (int)p.ldx; sg.soft = p.lse ? 1 : 0; sg.gsel = p.gsel;
-            sg.n0 = tn * BN; sg.ncl = p.N - 4; sg.t0 = t0; sg.vbeg = v; sg.vend = v + (t1 - t0); sg.slot = slot; sg.rv = p.rows_valid > 0 ? p.rows_valid : p.rows;
-            if (n < TN8_MAX_SEG) segs[n++] = sg;
-            v += t1 - t0;
-        };
-        if (a.do_al && w < a.al_wgs) {
-            const int tile = w / a.S, z = w - tile * a.S;
-            const int steps = a.p[0].rows / BK;
-            const int g0 = (int)((long long)steps * z / a.S), g1 = (int)((long long)steps * (z + 1) / a.S);
-            if (g1 > g0) put(0, tile, g0, g1, w);
-        }
-        if (a.do_rest) {
-            long long g = (long long)w * a.R;
-            const long long gend = min(g + a.R, (long long)a.rest_pre[a.np]);
-            int pr = a.n_al;
-            while (g < gend) {
-                while (pr + 1 < a.np && g >= a.rest_pre[pr + 1]) ++pr;
-                const int local = (int)(g - a.rest_pre[pr]);
-                const int tile = local / a.rest_steps[pr], t0 = local - tile * a.rest_steps[pr];
-                const int t1 = (int)min((long long)a.rest_steps[pr], t0 + (gend - g));
-                put(pr, tile, t0, t1, a.al_wgs + a.rest_tile0[pr] + tile + w);
-                g += t1 - t0;
-            }
-        }
-        s_nseg = n; s_vtot = v;
-    }
+    if (tid == 0) tn8_pieces(a, w, segs, &s_nseg, &s_vtot);
     if (a.do_rest) {                                            // row-gather tables of the per-triplet problems
         for (int i = tid; i < a.B; i += T) { lds_idx[i] = a.idx_ob ? a.idx_ob[i] : 0; lds_idx[a.B + i] = a.aid ? a.aid[i] : 0; }
     }
@@ -263,9 +266,219 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
 }
 
 
+// ---- the same launch on the bf16 matrix path with fp32-grade operands (NCX_F_X6; not the default) -----------------------------------------
+// Every operand element is cut into three bf16 values by truncation, x = x1 + x2 + x3 EXACTLY (x1 = x & 0xFFFF0000, x2 = (x - x1) & 0xFFFF0000,
+// x3 = x - x1 - x2; every residual is exact in fp32), when it is stored to LDS (once per element, as in the fp32 kernel); the six products
+// a1 x1 + (a1 x2 + a2 x1) + (a1 x3 + a2 x2 + a3 x1) run on v_mfma_f32_16x16x32_bf16 with fp32 accumulation (products of bf16 values are exact in
+// fp32): what is dropped is 2^-24 relative, the rounding error of one fp32 operation.  6 MFMAs of 16 cycles replace 8 of 32 per 16 x 16 x 32
+// block.  LDS holds three bf16 planes per operand in the global [k][m] layout; fragments come from ds_read_b64_tr_b16 (hardware transpose);
+// row pitches = 32 mod 256 bytes.  Measured on the dGt problem alone (tools/mb/mb_tn.hip): 80 us against 109, same error against fp64 (1.0e-9 on
+// values of 1.9e-3); the kernel is then bound by LDS + global-load return traffic (~3 000 cycles per k-step against 1 536 of MFMA), not by the
+// matrix cores.  Pieces, slab slots and the reduction are those of k_dw_tn8; the block mapping inside a wave is the plain one (block (i, j) =
+// rows wm0 + 16 i .., columns wn0 + 16 j ..), so the summation order differs from the fp32 kernel's: results agree to fp32 rounding, not bitwise.
+typedef __bf16 tn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short tn_s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int tn_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int TN6_PA = 544, TN6_PB = 160;                                    // bytes per k-row of one plane (512 + 32, 128 + 32)
+constexpr int TN6_PL = TN8_BK * (TN6_PA + TN6_PB), TN6_BUF = 3 * TN6_PL;    // one plane (A rows | X rows), one buffer
+
+__global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8_x6(const Tn8Args a) {
+    constexpr int T = TN8_T, BM = TN8_BM, BN = TN8_BN, BK = TN8_BK, PA = TN6_PA, PB = TN6_PB, PL = TN6_PL, BUF = TN6_BUF, A_PL = BK * PA;
+    constexpr int NA = 4;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char tn6_smem[];
+    Tn8Seg* const segs = (Tn8Seg*)(tn6_smem + 2 * BUF);          // [TN8_MAX_SEG]
+    int* const lds_idx = (int*)(segs + TN8_MAX_SEG);            // [2][B]
+    __shared__ int s_nseg, s_vtot;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int wm0 = 64 * (wave >> 1), wn0 = 32 * (wave & 1);
+    const int w = blockIdx.x;
+    if (tid == 0) tn8_pieces(a, w, segs, &s_nseg, &s_vtot);
+    if (a.do_rest) {
+        for (int i = tid; i < a.B; i += T) { lds_idx[i] = a.idx_ob ? a.idx_ob[i] : 0; lds_idx[a.B + i] = a.aid ? a.aid[i] : 0; }
+    }
+    __syncthreads();
+    const int nseg = s_nseg, V = s_vtot;
+    if (V == 0) return;
+
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- loader: as in k_dw_tn8 ---------------------------------------------------------------------------------------------------------
+    const int arow = tid >> 6, aq = tid & 63;
+    const int brow = tid >> 4, bq = tid & 15;
+    f32x4 va[2][NA], vb[2];
+    float vl[2], vs[2];
+    int qi = 0;
+    Tn8Seg dn = segs[0];
+    auto gather_row = [&](const Tn8Seg& sg, int v) __attribute__((always_inline)) -> int {
+        const int r = (sg.t0 + (min(v, V - 1) - sg.vbeg)) * BK + brow;
+        return lds_idx[(sg.gsel == 2 ? a.B : 0) + (sg.gsel ? min(r, a.B - 1) : 0)];
+    };
+    int rgn = gather_row(dn, 0);
+    auto issue = [&](auto set_c, int v) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_c)::value;
+        const int vv = min(v, V - 1);
+        const int t = dn.t0 + (vv - dn.vbeg);
+        const long long r0 = (long long)t * BK;
+        const tn_gfptr ap = (tn_gfptr)(uintptr_t)dn.a_ptr + (r0 + arow) * a.H + 4 * aq;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) va[S][i] = *(tn_gf4ptr)(ap + (long long)(8 * i) * a.H);
+        const int r = (int)r0 + brow;
+        const long long xr = dn.gsel ? (long long)rgn : (long long)min(r, dn.rv - 1);
+        vb[S] = *(tn_gf4ptr)((tn_gfptr)(uintptr_t)dn.x_ptr + xr * dn.ldx + min(dn.n0 + 4 * bq, dn.ncl));
+        vl[S] = ((tn_gfptr)(uintptr_t)dn.l_ptr)[dn.soft ? min(r, dn.rv - 1) : 0];
+        vs[S] = dn.soft ? 1.f : 0.f;
+        qi += (v + 1 >= dn.vend && qi + 1 < nseg) ? 1 : 0;
+        dn = segs[qi];
+        rgn = gather_row(dn, v + 1);
+    };
+    // x -> three bf16 planes (four values: one 8-byte store per plane)
+    auto split_store = [&](f32x4 v, unsigned char* base) __attribute__((always_inline)) {
+        unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xj = v[j];               // (a scalar copy first: __builtin_bit_cast applied to the vector element itself reads element 0 -- hipcc 7.2)
+            p1[j] = __builtin_bit_cast(unsigned, xj) & 0xFFFF0000u;
+            const float r1 = xj - __builtin_bit_cast(float, p1[j]);
+            p2[j] = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+            const float r2 = r1 - __builtin_bit_cast(float, p2[j]);
+            p3[j] = __builtin_bit_cast(unsigned, r2);            // (at most 8 significant bits are left: the high half holds them all)
+        }
+        // v_perm_b32: the high halves of two dwords -> one dword (the even element in the low half)
+        const tn_u32x2 w1 = {__builtin_amdgcn_perm(p1[1], p1[0], 0x07060302u), __builtin_amdgcn_perm(p1[3], p1[2], 0x07060302u)};
+        const tn_u32x2 w2 = {__builtin_amdgcn_perm(p2[1], p2[0], 0x07060302u), __builtin_amdgcn_perm(p2[3], p2[2], 0x07060302u)};
+        const tn_u32x2 w3 = {__builtin_amdgcn_perm(p3[1], p3[0], 0x07060302u), __builtin_amdgcn_perm(p3[3], p3[2], 0x07060302u)};
+        *(tn_u32x2*)(base) = w1; *(tn_u32x2*)(base + PL) = w2; *(tn_u32x2*)(base + 2 * PL) = w3;
+    };
+    auto stash = [&](auto set_c, int buf, int h0, int h1) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_c)::value;
+        unsigned char* const base = tn6_smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (i < h0 || i >= h1) continue;
+            split_store(va[S][i], base + (arow + 8 * i) * PA + aq * 8);
+        }
+        if (NA >= h0 && NA < h1) {
+            f32x4 v = vb[S], e;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float xj = v[j]; e[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(xj, 1.44269504088896341f, -vl[S])); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float xj = v[j], ej = e[j]; v[j] = vs[S] != 0.f ? ej : xj; }
+            split_store(v, base + A_PL + brow * PB + bq * 8);
+        }
+    };
+    typedef __attribute__((address_space(3))) tn_s16x4* lds_s16x4;
+    const int tq = li >> 2, tp = li & 3;
+    const int offA = (4 * lk + tq) * PA + (wm0 + 4 * tp) * 2, offB = A_PL + (4 * lk + tq) * PB + (wn0 + 4 * tp) * 2;
+    auto read_a = [&](int buf, int i, tn_bf16x8 (&af)[3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const unsigned char* ta = tn6_smem + buf * BUF + p * PL + offA + i * 32;
+            const tn_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ta));
+            const tn_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ta + 16 * PA));
+            af[p] = __builtin_bit_cast(tn_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+    };
+    auto read_b = [&](int buf, tn_bf16x8 (&bf)[3][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned char* tb = tn6_smem + buf * BUF + p * PL + offB + j * 32;
+                const tn_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tb));
+                const tn_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tb + 16 * PB));
+                bf[p][j] = __builtin_bit_cast(tn_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+    };
+    // the 12 MFMAs of block row i: the two column blocks alternate (a dependent MFMA is two issues away); small terms first
+    auto mfma12 = [&](const tn_bf16x8 (&af)[3], const tn_bf16x8 (&bf)[3][2], f32x4 (&c)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[2][j], c[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[1][j], c[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[0][j], c[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[1][j], c[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[0][j], c[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[0][j], c[j], 0, 0, 0);
+    };
+    auto pin = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    typedef std::integral_constant<int, 0> S0; typedef std::integral_constant<int, 1> S1;
+    tn_bf16x8 afA[3], afB[3], bfr[2][3][2];
+    const tn_bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        afB[p] = zero8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bfr[1][p][j] = zero8;
+    }
+    issue(S0{}, 0);
+    issue(S1{}, 1);
+    stash(S0{}, 0, 0, NA + 1);
+    issue(S0{}, 2);
+    __syncthreads();
+    int qc = 0, vend_c = segs[0].vend, slot_c = segs[0].slot;
+    auto flush = [&]() __attribute__((always_inline)) {          // partial tile -> its slab slot (lane: row 4 lk + rg of block row i, column li of block column j)
+        float* const slot = a.slab + (long long)slot_c * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int row = wm0 + 16 * i + 4 * lk + rg;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) { slot[row * BN + wn0 + 16 * j + li] = acc[i][j][rg]; acc[i][j][rg] = 0.f; }
+            }
+    };
+    auto step = [&](auto par_c, int v) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_c)::value;
+        typedef std::integral_constant<int, PAR ^ 1> SS;
+        // block row 3 of step v - 1 (zeros at the start and after a flush) over the first reads of this buffer
+        read_b(PAR, bfr[PAR]);
+        read_a(PAR, 0, afA);
+        mfma12(afB, bfr[PAR ^ 1], acc[3]);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(PAR, 1, afB); stash(SS{}, PAR ^ 1, 0, 2); mfma12(afA, bfr[PAR], acc[0]); pin();
+        read_a(PAR, 2, afA); stash(SS{}, PAR ^ 1, 2, NA + 1); mfma12(afB, bfr[PAR], acc[1]); pin();
+        read_a(PAR, 3, afB); issue(SS{}, v + 3); mfma12(afA, bfr[PAR], acc[2]); pin();
+        __syncthreads();
+        if (v + 1 == vend_c) {                           // the piece ends here (uniform): block row 3, partial tile out, next piece
+            mfma12(afB, bfr[PAR], acc[3]);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) afB[p] = zero8;
+            flush();
+            ++qc;
+            if (qc < nseg) { vend_c = segs[qc].vend; slot_c = segs[qc].slot; }
+        }
+    };
+    int v = 0;
+    for (; v + 1 < V; v += 2) { step(S0{}, v); step(S1{}, v + 1); }
+    if (v < V) step(S0{}, v);
+}
+
 // ---- host ------------------------------------------------------------------------------------------------------------------------------
 static inline int tn8_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// NCX_F_X6: the launch runs on the bf16 matrix path with three-plane operands (k_dw_tn8_x6); the row-gather tables share LDS with six planes
+constexpr int TN6_MAX_B = 2048;
+bool dw_tn8_x6(const ncx_dims& d) { return (d.flags & NCX_F_X6) && d.B <= TN6_MAX_B && !hook_env("NCX_NO_X6"); }
 bool dw_tn8_supported(const ncx_dims& d) { return !(d.flags & NCX_F_BF16) && dw_tn8_shapes_ok(d); }
 // the bf16 variant keeps the per-triplet shared segments of linear_1 in fp32: their weight gradient takes this kernel too (rest sequence only)
 bool dw_tn8_shapes_ok(const ncx_dims& d) {
@@ -355,6 +568,14 @@ int dw_tn8_products(const ncx_dims& d, const Tn8Prob* probs, int np, int n_al, b
     *red = r;
     if (!a.do_al && !a.do_rest) { red->n_tiles_total = 0; return NCX_OK; }
     a.idx_ob = idx_ob; a.aid = aid;
+    if (dw_tn8_x6(d)) {
+        const int lds = 2 * TN6_BUF + TN8_MAX_SEG * (int)sizeof(Tn8Seg) + 2 * d.B * 4;
+        static DevMask attr6{0};
+        NCX_HIP_TRY(set_max_lds_once(attr6, (const void*)k_dw_tn8_x6, 2 * TN6_BUF + TN8_MAX_SEG * (int)sizeof(Tn8Seg) + 2 * TN6_MAX_B * 4));
+        hipLaunchKernelGGL(k_dw_tn8_x6, dim3(pl.grid), dim3(TN8_T), lds, s, a);
+        NCX_HIP_TRY(hipGetLastError());
+        return NCX_OK;
+    }
     const int lds = 2 * TN8_BK * (TN8_PA + TN8_PB) * 4 + TN8_MAX_SEG * (int)sizeof(Tn8Seg) + 2 * d.B * 4;
     static DevMask attr{0};
     NCX_HIP_TRY(set_max_lds_once(attr, (const void*)k_dw_tn8, 2 * TN8_BK * (TN8_PA + TN8_PB) * 4 + TN8_MAX_SEG * (int)sizeof(Tn8Seg) + 2 * 4096 * 4));

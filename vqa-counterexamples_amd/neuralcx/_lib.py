@@ -14,6 +14,7 @@ NCX_F_V_MULT, NCX_F_V_DIST, NCX_F_V_RANK, NCX_F_A_EMB = 1, 2, 4, 8
 NCX_F_ALL = 15
 NCX_F_REUSE_GT = 32   # evaluation: Gt in the workspace is still valid (same weights)
 NCX_F_FUSED_TAIL = 64  # training: out layer + loss / Recall + head of the backward in one pass (ncx_train_tail)
+NCX_F_X6 = 128         # NOT the default: the balanced TN weight-gradient launch on the bf16 matrix path with three-plane (fp32-grade) operands
 NCX_F_BF16 = 16       # BASELINE configs[4]: bf16 operands for the two dominant GEMMs (include/neuralcx.h)
 
 EXPORTS = ("ncx_input_size", "ncx_workspace_bytes", "ncx_forward", "ncx_forward_phase", "ncx_loss_rank", "ncx_backward", "ncx_backward_phase",

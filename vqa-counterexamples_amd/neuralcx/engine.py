@@ -16,7 +16,7 @@ from typing import Dict, Optional
 import torch
 
 from . import dp, ops
-from ._lib import NCX_F_ALL, NCX_F_A_EMB, NCX_F_BF16, NCX_F_FUSED_TAIL, NCX_F_REUSE_GT
+from ._lib import NCX_F_ALL, NCX_F_A_EMB, NCX_F_BF16, NCX_F_FUSED_TAIL, NCX_F_REUSE_GT, NCX_F_X6
 
 STATE_NAMES = ("answer_embedding.weight", "linear_1.weight", "linear_1.bias", "linear_2.weight", "linear_2.bias",
                "linear_3.weight", "linear_3.bias", "out.weight", "out.bias")
@@ -57,7 +57,7 @@ class FlatParams:
 
 class NeuralCXEngine:
     def __init__(self, K=24, dv=2048, dq=2400, dz=360, da=2400, A=2000, H=256, L=1, drop_p=0.25, lr=1e-4,
-                 device="cuda:0", spec: Optional[dict] = None, world_size=1, process_group=None, bf16: bool = False):
+                 device="cuda:0", spec: Optional[dict] = None, world_size=1, process_group=None, bf16: bool = False, x6: bool = False):
         self.cfg = dict(K=K, dv=dv, dq=dq, dz=dz, da=da, A=A, H=H, L=L)
         self.drop_p, self.lr = drop_p, lr
         self.device = torch.device(device)
@@ -66,6 +66,8 @@ class NeuralCXEngine:
             if self.flags != NCX_F_ALL:
                 raise ValueError("the bf16 variant supports the full model_spec only (no lesions)")
             self.flags |= NCX_F_BF16
+        if x6:                                    # NOT the default: fp32-grade split-bf16 operands for the balanced TN weight-gradient launch
+            self.flags |= NCX_F_X6
         self.params = FlatParams(param_shapes(**self.cfg), self.device)
         self.grads = self.params.like()
         self.exp_avg = torch.zeros_like(self.params.flat)

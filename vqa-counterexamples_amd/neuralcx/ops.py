@@ -13,6 +13,8 @@ from typing import Dict, Optional
 
 import torch
 
+import os
+
 from . import _lib
 from ._lib import (NCX_F_A_EMB, NCX_F_ALL, NCX_F_V_DIST, NCX_F_V_MULT, NCX_F_V_RANK, NcxDims, NcxGrads,
                    NcxInputs, NcxMutanParams, NcxParams)
@@ -89,6 +91,11 @@ class Batch:
         return s
 
 
+# Flag bits OR-ed into every ncx_dims built here.  NCX_X6=1 in the environment puts the whole process on the split-bf16 ("bf16 x 6") variant
+# of the balanced TN weight-gradient launch (include/neuralcx.h: NCX_F_X6; not the default) -- how the unchanged GPU suite is run against it.
+EXTRA_FLAGS = _lib.NCX_F_X6 if os.environ.get("NCX_X6", "0") not in ("", "0") else 0
+
+
 def make_dims(batch: Batch, H: int, L: int, da: int, A: int, flags: int = NCX_F_ALL, training: bool = False,
               drop_p: float = 0.0, loss_scale: float = 0.0, seed: int = 0) -> NcxDims:
     B, K1 = batch.img_idx.shape
@@ -97,7 +104,7 @@ def make_dims(batch: Batch, H: int, L: int, da: int, A: int, flags: int = NCX_F_
     d.dv, d.dq, d.dz = batch.feats.shape[1], batch.q_emb.shape[1], batch.z_orig.shape[1]
     d.da, d.A, d.H, d.L = da, A, H, L
     d.n_img = batch.feats.shape[0]
-    d.flags, d.training, d.drop_p, d.loss_scale, d.seed = flags, int(training), float(drop_p), float(loss_scale), int(seed) & (2 ** 64 - 1)
+    d.flags, d.training, d.drop_p, d.loss_scale, d.seed = flags | EXTRA_FLAGS, int(training), float(drop_p), float(loss_scale), int(seed) & (2 ** 64 - 1)
     # shape validation before any launch (the reference's asserts: cx.py:65,263)
     K = d.K
     assert batch.z_knns.shape == (B, K, d.dz), batch.z_knns.shape
