@@ -713,6 +713,7 @@ def test_x6_runs_and_agrees_with_the_fp32_kernels_to_rounding(monkeypatch):
     from neuralcx import _lib, ops
     d = orc.Dims()
     params, batch = _full_size_case(d, 512, 77)
+    monkeypatch.setattr(ops, "EXTRA_FLAGS", 0)                       # (the suite may itself be running under NCX_X6=1)
     _, _, g32 = run_hip(d, None, params, batch)
     monkeypatch.setattr(ops, "EXTRA_FLAGS", _lib.NCX_F_X6)
     _, _, g6 = run_hip(d, None, params, batch)
@@ -724,3 +725,16 @@ def test_x6_runs_and_agrees_with_the_fp32_kernels_to_rounding(monkeypatch):
     assert differs
     for k in ("linear_1.bias", "out.weight"):
         assert np.array_equal(g32[k], g6[k])
+
+
+@pytest.mark.parametrize("B,K,H,L,dv", [(1, 24, 256, 1, 64), (7, 24, 256, 2, 128), (13, 48, 256, 1, 192), (37, 24, 512, 1, 64)])
+def test_x6_fused_v_gradient_kernel_vs_oracle(B, K, H, L, dv, monkeypatch, x6):
+    """k_dw_km_x6 (the per-triplet fold pass on the bf16 matrix path with three-plane operands) takes H = multiples of 256 and dv = multiples
+    of 64 under NCX_F_X6: forced on small batches (chunks of one triplet, empty chunks, an odd number of reduction steps per chunk, K = 48 =
+    two 24-row steps per triplet, two row tiles) and compared with the oracle at the suite's tolerances."""
+    monkeypatch.setenv("NCX_EXPERIMENT", "1")
+    monkeypatch.setenv("NCX_KM_FORCE", "1")
+    d = orc.Dims(K=K, dv=dv, dq=50, dz=18, A=45, H=H, L=L)
+    params = orc.init_params(d, seed=23 + B, gain=3.0)
+    batch = random_case(700 + B, B, d)
+    compare_with_oracle(d, None, params, batch)

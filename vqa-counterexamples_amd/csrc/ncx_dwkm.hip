@@ -242,6 +242,214 @@ __global__ __launch_bounds__(T, OCC) void k_dw_km(const float* __restrict__ dpre
         }
 }
 
+
+// ---- the same pass on the bf16 matrix path with fp32-grade operands (NCX_F_X6; not the default) -------------------------------------------
+// Operands as in k_dw_tn8_x6 (ncx_dwtn.hip): every fp32 element is cut into three bf16 values by truncation when it is stored to LDS
+// (x = x1 + x2 + x3 exactly), six products per block on v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  One 8-wave workgroup per CU on a
+// 256 (all of H) x 64 tile pair; a reduction step is one triplet part of 24 rows in a 32-deep MFMA step (LDS rows 24 .. 31 of the dpre planes
+// are zeroed once and never written: their products vanish whatever the feature planes hold there).  T_b of a 16-row block row comes out of
+// its 12 MFMAs into a scratch accumulator that starts at zero, and is folded into both outputs (acc_k += T_b, acc_m += v_o (.) T_b) under the
+// MFMAs of the NEXT block row; the last block row's MFMAs of a step run after the barrier, over the first fragment reads of the next step.
+// v_o travels in fp32 (a 64-float row per LDS buffer).  Same k-chunks and slab layout as k_dw_km: the reduction that follows is unchanged.
+typedef __bf16 km_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short km_s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int km_u32x2 __attribute__((ext_vector_type(2)));
+constexpr int KM6_PA = 544, KM6_PB = 160;                                    // bytes per row of one plane (512 + 32, 128 + 32)
+constexpr int KM6_PL = 32 * (KM6_PA + KM6_PB), KM6_BUF = 3 * KM6_PL;
+constexpr int KM6_LDS = 2 * KM6_BUF + 2 * 64 * 4 + 64 * 16;                  // planes, v_o rows, a dump row for the stores of threads without a v_o quad
+
+__global__ __launch_bounds__(512, 1) void k_dw_km_x6(const float* __restrict__ dpre, int H, const float* __restrict__ feats, int dv,
+                                                     const int* __restrict__ idx_k, const int* __restrict__ idx_o, int B, int Kc,
+                                                     int chunk, int tiles_m, int S, float* __restrict__ slab) {
+    constexpr int T = 512, BM = 256, BN = 64, K = 24, PA = KM6_PA, PB = KM6_PB, PL = KM6_PL, BUF = KM6_BUF, A_PL = 32 * PA;
+    constexpr int NA = 3;                                          // dpre quads per thread and step: rows arow + 8 i
+    extern __shared__ __attribute__((aligned(1024))) unsigned char km6_smem[];
+    float* const lds_vo = (float*)(km6_smem + 2 * BUF);           // [2][64]
+    float* const lds_dump = lds_vo + 2 * 64;                      // [64][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int wm0 = 64 * (wave >> 1), wn0 = 32 * (wave & 1);
+    const int z = blockIdx.x % S, t = blockIdx.x / S;
+    const int tm = t % tiles_m, tn = t / tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int spt = Kc / K;
+    const int t0 = z * chunk, t1 = min(t0 + chunk, B);
+    if (t0 >= B) return;
+    const int b0 = t0 * spt, b1 = t1 * spt;
+    for (int i = tid; i < 2 * BUF / 16; i += T) ((f32x4*)km6_smem)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    f32x4 acc_k[4][2], acc_m[4][2], tt[2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { acc_k[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_m[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) tt[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int arow = tid >> 6, aq = tid & 63;
+    const int brow = tid >> 4, bq = tid & 15;                      // rows 0 .. 23: v_k of the step's rows; rows 24 .. 31: the triplet's v_o (same quad, same value)
+    typedef const __attribute__((address_space(1))) float* gfp;
+    typedef const __attribute__((address_space(1))) f32x4u* gf4p;
+    typedef const __attribute__((address_space(1))) int* gip;
+    f32x4 va[2][NA], vb[2];
+    auto load_idx = [&](int b) __attribute__((always_inline)) -> int {
+        const long long r0 = (long long)min(b, b1 - 1) * K;
+        return brow < K ? ((gip)idx_k)[r0 + brow] : ((gip)idx_o)[r0];
+    };
+    int ixn = load_idx(b0);                                        // gather row of the NEXT issue (requested one issue ahead)
+    auto issue = [&](auto set_c, int b) __attribute__((always_inline)) {
+        constexpr int SS_ = decltype(set_c)::value;
+        const long long r0 = (long long)min(b, b1 - 1) * K;
+        const gfp ap = (gfp)dpre + (r0 + arow) * H + m0 + 4 * aq;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) va[SS_][i] = *(gf4p)(ap + (long long)(8 * i) * H);
+        vb[SS_] = *(gf4p)((gfp)feats + (long long)ixn * dv + n0 + 4 * bq);
+        ixn = load_idx(b + 1);
+    };
+    auto split_store = [&](f32x4 v, unsigned char* base) __attribute__((always_inline)) {
+        unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xj = v[j];               // (a scalar copy first: __builtin_bit_cast applied to the vector element itself reads element 0 -- hipcc 7.2)
+            p1[j] = __builtin_bit_cast(unsigned, xj) & 0xFFFF0000u;
+            const float r1 = xj - __builtin_bit_cast(float, p1[j]);
+            p2[j] = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+            const float r2 = r1 - __builtin_bit_cast(float, p2[j]);
+            p3[j] = __builtin_bit_cast(unsigned, r2);
+        }
+        const km_u32x2 w1 = {__builtin_amdgcn_perm(p1[1], p1[0], 0x07060302u), __builtin_amdgcn_perm(p1[3], p1[2], 0x07060302u)};
+        const km_u32x2 w2 = {__builtin_amdgcn_perm(p2[1], p2[0], 0x07060302u), __builtin_amdgcn_perm(p2[3], p2[2], 0x07060302u)};
+        const km_u32x2 w3 = {__builtin_amdgcn_perm(p3[1], p3[0], 0x07060302u), __builtin_amdgcn_perm(p3[3], p3[2], 0x07060302u)};
+        *(km_u32x2*)(base) = w1; *(km_u32x2*)(base + PL) = w2; *(km_u32x2*)(base + 2 * PL) = w3;
+    };
+    // the fp32 v_o quad goes to the buffer's v_o row from the threads that hold one (rows >= 24; eight copies of the same value), to the dump row from the others: no branch
+    float* const vo_dst0 = brow >= K ? lds_vo + 4 * bq : lds_dump + 4 * lane;
+    const int vo_step = brow >= K ? 64 : 0;
+    auto stash = [&](auto set_c, int buf, int h0, int h1) __attribute__((always_inline)) {
+        constexpr int SS_ = decltype(set_c)::value;
+        unsigned char* const base = km6_smem + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (i < h0 || i >= h1) continue;
+            split_store(va[SS_][i], base + (arow + 8 * i) * PA + aq * 8);
+        }
+        if (NA >= h0 && NA < h1) {
+            split_store(vb[SS_], base + A_PL + brow * PB + bq * 8);
+            *(f32x4*)(vo_dst0 + buf * vo_step) = vb[SS_];
+        }
+    };
+    typedef __attribute__((address_space(3))) km_s16x4* lds_s16x4;
+    const int tq = li >> 2, tp = li & 3;
+    const int offA = (4 * lk + tq) * PA + (wm0 + 4 * tp) * 2, offB = A_PL + (4 * lk + tq) * PB + (wn0 + 4 * tp) * 2;
+    auto read_a = [&](int buf, int i, km_bf16x8 (&af)[3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const unsigned char* ta = km6_smem + buf * BUF + p * PL + offA + i * 32;
+            const km_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ta));
+            const km_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ta + 16 * PA));
+            af[p] = __builtin_bit_cast(km_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+    };
+    auto read_b = [&](int buf, km_bf16x8 (&bf)[3][2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const unsigned char* tb = km6_smem + buf * BUF + p * PL + offB + j * 32;
+                const km_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tb));
+                const km_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tb + 16 * PB));
+                bf[p][j] = __builtin_bit_cast(km_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+    };
+    // T of one block row: 12 MFMAs from zero, the two column blocks alternate, small terms first
+    auto mfma12z = [&](const km_bf16x8 (&af)[3], const km_bf16x8 (&bf)[3][2], f32x4 (&c)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[2][j], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[1][j], c[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[0][j], c[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[1][j], c[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[0][j], c[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[0][j], c[j], 0, 0, 0);
+    };
+    auto fold = [&](int i, const f32x4 (&c)[2], const float (&vo)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc_k[i][j][q] += c[j][q];
+                acc_m[i][j][q] = __builtin_fmaf(c[j][q], vo[j], acc_m[i][j][q]);
+            }
+    };
+    auto pin = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 12; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    typedef std::integral_constant<int, 0> S0; typedef std::integral_constant<int, 1> S1;
+    km_bf16x8 afA[3], afB[3], bfr[2][3][2];
+    float vo[2][2] = {{0.f, 0.f}, {0.f, 0.f}};                      // [parity of the step][column block]: v_o of the lane's columns
+    const km_bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        afB[p] = zero8;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bfr[1][p][j] = zero8;
+    }
+    issue(S0{}, b0);
+    issue(S1{}, b0 + 1);
+    stash(S0{}, 0, 0, NA + 1);
+    issue(S0{}, b0 + 2);
+    __syncthreads();
+    auto step = [&](auto par_c, int b) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_c)::value;
+        typedef std::integral_constant<int, PAR ^ 1> SS;
+        // block row 3 of the previous step (zeros at the start) over the first reads of this buffer; the fold of its block row 2
+        read_b(PAR, bfr[PAR]);
+        read_a(PAR, 0, afA);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) vo[PAR][j] = lds_vo[PAR * 64 + wn0 + 16 * j + li];
+        mfma12z(afB, bfr[PAR ^ 1], tt[1]);
+        fold(2, tt[0], vo[PAR ^ 1]);
+#pragma unroll
+        for (int q = 0; q < 12; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(PAR, 1, afB); stash(SS{}, PAR ^ 1, 0, 2); mfma12z(afA, bfr[PAR], tt[0]); fold(3, tt[1], vo[PAR ^ 1]); pin();
+        read_a(PAR, 2, afA); stash(SS{}, PAR ^ 1, 2, NA + 1); mfma12z(afB, bfr[PAR], tt[1]); fold(0, tt[0], vo[PAR]); pin();
+        read_a(PAR, 3, afB); issue(SS{}, b + 3); mfma12z(afA, bfr[PAR], tt[0]); fold(1, tt[1], vo[PAR]); pin();
+        __syncthreads();
+    };
+    int b = b0;
+    for (; b + 1 < b1; b += 2) { step(S0{}, b); step(S1{}, b + 1); }
+    if (b < b1) { step(S0{}, b); mfma12z(afB, bfr[0], tt[1]); fold(2, tt[0], vo[0]); fold(3, tt[1], vo[0]); }
+    else { mfma12z(afB, bfr[1], tt[1]); fold(2, tt[0], vo[1]); fold(3, tt[1], vo[1]); }
+    float* dk = slab + ((long long)z * 2 + 0) * H * dv;
+    float* dm = slab + ((long long)z * 2 + 1) * H * dv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long long m = m0 + wm0 + 16 * i + 4 * lk + q;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn0 + 16 * j + li;
+                dk[m * dv + n] = acc_k[i][j][q]; dm[m * dv + n] = acc_m[i][j][q];
+            }
+        }
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_dw_km_reduce(const KmReduceArgs r) { km_reduce_body<VEC>(r, blockIdx.x); }
 // ... and, in the same launch, the split fix-up of the grouped GEMM that computes the other columns of linear_1's gradient
@@ -316,6 +524,13 @@ int dw_km(const ncx_dims& d, const float* dpre, const float* feats, const int* i
     int chunk;
     const int S = km_chunks(d, chunk);
     constexpr int R = 24;
+    if ((d.flags & NCX_F_X6) && d.H % 256 == 0 && d.dv % 64 == 0 && !hook_env("NCX_NO_X6") && !hook_env("NCX_NO_KM_X6")) {      // (K % 24 == 0: dw_km_supported)
+        static DevMask attr6{0};
+        NCX_HIP_TRY(set_max_lds_once(attr6, (const void*)k_dw_km_x6, KM6_LDS));
+        hipLaunchKernelGGL(k_dw_km_x6, dim3((d.H / 256) * (d.dv / 64) * S), dim3(512), KM6_LDS, s, dpre, d.H, feats, d.dv, idx_k, idx_o, d.B, d.K, chunk, d.H / 256, S, slab);
+        NCX_HIP_TRY(hipGetLastError());
+        return finish ? dw_km_finish(d, slab, g_vother, g_vmult, din, nullptr, 0, s) : NCX_OK;
+    }
     // 128-row tiles at two workgroups per CU, or 64-row tiles at four (hook NCX_KM_BM=64)
     int bm = 128;
     if (const char* e = hook_env("NCX_KM_BM")) bm = atoi(e) == 64 ? 64 : 128;
