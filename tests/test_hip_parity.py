@@ -708,8 +708,8 @@ def test_x6_phased_backward_is_bit_identical(x6):
 
 def test_x6_runs_and_agrees_with_the_fp32_kernels_to_rounding(monkeypatch):
     """The flag really switches kernels (another summation order: not bitwise equal), and what it computes is the fp32 result to fp32
-    rounding: at configs[1]'s full size every weight-gradient element of linear_1 and the answer embedding within 2e-6 of its tensor's max
-    of the fp32 kernels' (the suite's bound against the oracle is 1e-4 of the max)."""
+    rounding: at configs[1]'s full size every gradient element within 2e-6 of its tensor's max of the fp32 kernels' (the suite's bound
+    against the oracle is 1e-4 of the max)."""
     from neuralcx import _lib, ops
     d = orc.Dims()
     params, batch = _full_size_case(d, 512, 77)
@@ -718,13 +718,11 @@ def test_x6_runs_and_agrees_with_the_fp32_kernels_to_rounding(monkeypatch):
     monkeypatch.setattr(ops, "EXTRA_FLAGS", _lib.NCX_F_X6)
     _, _, g6 = run_hip(d, None, params, batch)
     differs = False
-    for k in ("linear_1.weight", "answer_embedding.weight"):
+    for k in g32:                                    # (the forward's first layer runs on the split operands too: every gradient moves, by rounding)
         a, b = g32[k], g6[k]
         differs |= not np.array_equal(a, b)
-        assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max(), (k, np.abs(a - b).max(), np.abs(a).max())
+        assert np.abs(a - b).max() <= 2e-6 * max(np.abs(a).max(), 1e-30), (k, np.abs(a - b).max(), np.abs(a).max())
     assert differs
-    for k in ("linear_1.bias", "out.weight"):
-        assert np.array_equal(g32[k], g6[k])
 
 
 @pytest.mark.parametrize("B,K,H,L,dv", [(1, 24, 256, 1, 64), (7, 24, 256, 2, 128), (13, 48, 256, 1, 192), (37, 24, 512, 1, 64)])
@@ -738,3 +736,32 @@ def test_x6_fused_v_gradient_kernel_vs_oracle(B, K, H, L, dv, monkeypatch, x6):
     params = orc.init_params(d, seed=23 + B, gain=3.0)
     batch = random_case(700 + B, B, d)
     compare_with_oracle(d, None, params, batch)
+
+
+@pytest.mark.parametrize("H", [64, 300])
+@pytest.mark.parametrize("K", [24, 48])
+def test_x6_forward_192_row_form_vs_oracle(K, H, monkeypatch, x6):
+    """Under NCX_F_X6 the segments after the per-triplet fold (dist | rank, z_k, softmax(a_k) . Gt) of the 192-row forward form run on the bf16
+    matrix path with three-plane operands: forced at a small size (B = 9: a ragged row tile; H = 300: a ragged column tile), logits against the
+    oracle at the suite's 1e-4; not bit-identical to the fp32 form (another summation order), but equal to it to fp32 rounding."""
+    from neuralcx import ops
+    monkeypatch.setenv("NCX_EXPERIMENT", "1")
+    monkeypatch.setenv("NCX_FOLD8", "1")
+    d = orc.Dims(K=K, dv=96 if H == 64 else 160, dq=64, dz=24, A=40, H=H, L=1)
+    params = orc.init_params(d, seed=5, gain=3.0)
+    batch = random_case(77, 9, d)
+    b, p = to_dev_batch(batch), to_dev_params(params)
+    dims = ops.make_dims(b, H=d.H, L=d.L, da=d.da, A=d.A)
+    ws = ops.alloc_workspace(dims, dev())
+    scores = ops.forward(dims, b, p, ws).cpu()
+    ref = orc.forward_faithful(params, d, *[batch[k] for k in ("image_features", "q_emb", "z_orig", "z_knns", "a_knns", "answer_aids")])
+    assert (scores - ref.reshape(scores.shape)).abs().max() <= 1e-4
+    monkeypatch.setattr(ops, "EXTRA_FLAGS", 0)
+    dims32 = ops.make_dims(b, H=d.H, L=d.L, da=d.da, A=d.A)
+    s32 = ops.forward(dims32, b, p, ws).cpu()
+    assert not torch.equal(scores, s32)
+    assert (scores - s32).abs().max() <= 2e-6 * max(1.0, float(s32.abs().max()))
+
+
+def test_x6_configs1_unconditioned_logits_vs_oracle(x6):
+    test_configs1_unconditioned_logits_vs_oracle()

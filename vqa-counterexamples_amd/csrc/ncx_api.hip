@@ -1302,7 +1302,7 @@ static int forward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_para
         rc = bf16_main_forward(d, xc, (const u16*)(ws + w.wc), e, (float*)(ws + w.h[0]), s); if (rc) return rc;
         rc = prof_close(U_MAIN, s); if (rc) return rc;
     } else if (main_fwd_dims_ok(d)) {        // the fused forward kernel (ncx_main.h): weights zero-padded to 32 columns
-        MainArgs a{}; a.M = M; a.N = H;
+        MainArgs a{}; a.M = M; a.N = H; a.x6 = (d.flags & NCX_F_X6) && !hook_env("NCX_NO_X6") && !hook_env("NCX_NO_MAIN_X6");
         int n = 0;
         auto seg = [&](int kind, const float* x, long long lda, int klen, const int* i1, const int* i2, const float* lse, int slot, const float* wgt, long long ldb) {
             MainSeg& g = a.seg[n++]; g.kind = kind; g.a = x; g.lda = lda; g.idx = i1; g.idx2 = i2; g.lse = lse; g.klen = klen;

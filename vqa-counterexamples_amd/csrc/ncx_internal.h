@@ -100,6 +100,7 @@ struct MainArgs {
     // does not have to read the 200 MB of feature rows a second time
     float* dist_out; long long ld_dist;
     unsigned long long* stamps;      // diagnostics (tools/mb/mb_main.hip): 16 words per workgroup of s_memtime / s_memrealtime stamps; NULL in the library
+    int x6;                          // NCX_F_X6: the plain / softmax segments of the 192 x 64 fold form on the bf16 matrix path with three-plane operands
 };
 int main_forward(MainArgs& a, hipStream_t s);
 // k-split of a problem for the fused forward kernel (48 x 128 tiles): 1 when its tiles already give every CU a workgroup,

@@ -41,12 +41,16 @@ template <int V> struct IntC { static constexpr int value = V; };
 
 // BM x BN tile, T threads = T / 64 waves as WGM x WGN, DEPTH register sets of global loads in flight, OCC = waves per SIMD the register
 // budget is sized for (workgroups per CU x T / 256)
-template <int BM_, int BN_, int WGM_, int WGN_, int DEPTH_, int OCC_, int T_ = MF_T>
+// X6 (NCX_F_X6; not the default): the plain / softmax segments run on the bf16 matrix path with three-plane fp32-grade operands (see run_seg)
+constexpr int MF6_P = 80;                                            // bytes per 32-deep row of one bf16 plane (64 + 16: conflict-free ds_read_b128)
+template <int BM_, int BN_, int WGM_, int WGN_, int DEPTH_, int OCC_, int T_ = MF_T, bool X6_ = false>
 struct MainCfg {
     static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, DEPTH = DEPTH_, OCC = OCC_, T = T_;
+    static constexpr bool X6 = X6_;
     static constexpr int RP = T / 8;                                // tile rows per loader pass (8 threads x 16 bytes per 32-float row)
     static constexpr int BM_LDS = (BM + RP - 1) / RP * RP;        // A rows held in LDS (a multiple of the loader pass)
-    static constexpr int LDS = 2 * (BM_LDS + BN) * MF_P * 4;
+    static constexpr int LDS6 = 2 * 3 * (BM_LDS + BN) * MF6_P;      // X6: [2 buffers][3 planes][A rows | W rows][MF6_P]
+    static constexpr int LDS = X6_ && LDS6 > 2 * (BM_LDS + BN) * MF_P * 4 ? LDS6 : 2 * (BM_LDS + BN) * MF_P * 4;
     static constexpr int LDS_FOLD = BM % 96 == 0 ? 2 * (32 * (T / 64) + 128) * MF_P * 4   // MK_VFOLD, one triplet per wave: A 32 rows per wave, W_k | W_m 2 x 64 rows
                                                  : 2 * (80 + 2 * 64) * MF_P * 4;          // MK_VFOLD on 48-row tiles: A 80 rows, two effective weight tiles
 };
@@ -129,6 +133,73 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
                 for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
     };
 
+    // ---- X6: operands as three bf16 planes (x = x1 + x2 + x3 exactly, by truncation, cut when the tile is stored to LDS), six products per
+    // 16 x 16 x 32 block on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: what is dropped is 2^-24 relative.  A sub-step is one 16-row block
+    // row of the wave (6 WN MFMAs); the last block row of a step runs after the barrier, over the first reads of the next buffer.
+    constexpr bool X6 = CFG::X6;
+    static_assert(!X6 || (VFOLD && BM == 192 && WM == 3 && WN == 2 && DEPTH == 2), "X6: the 8-wave 192 x 64 fold form only");
+    typedef __bf16 mbf16x8 __attribute__((ext_vector_type(8)));
+    typedef unsigned int mu32x2 __attribute__((ext_vector_type(2)));
+    constexpr int P6 = MF6_P, A6_PL = BML * P6, PL6 = (BML + BN) * P6, BUF6 = 3 * PL6;
+    unsigned char* const lds6 = (unsigned char*)mf_smem;
+    mbf16x8 xa[2][3], xb[2][X6 ? WN : 1][3];             // [alternating set][plane]; [parity of the step][column block][plane]
+    if constexpr (X6) {
+        const mbf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                xa[q][p] = z8;
+#pragma unroll
+                for (int j = 0; j < WN; ++j) xb[q][j][p] = z8;
+            }
+    }
+    auto split_store6 = [&](f32x4 v, unsigned char* base) __attribute__((always_inline)) {
+        unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xj = v[j];               // (a scalar copy first: __builtin_bit_cast applied to the vector element itself reads element 0 -- hipcc 7.2)
+            p1[j] = __builtin_bit_cast(unsigned, xj) & 0xFFFF0000u;
+            const float r1 = xj - __builtin_bit_cast(float, p1[j]);
+            p2[j] = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+            const float r2 = r1 - __builtin_bit_cast(float, p2[j]);
+            p3[j] = __builtin_bit_cast(unsigned, r2);
+        }
+        const mu32x2 w1 = {__builtin_amdgcn_perm(p1[1], p1[0], 0x07060302u), __builtin_amdgcn_perm(p1[3], p1[2], 0x07060302u)};
+        const mu32x2 w2 = {__builtin_amdgcn_perm(p2[1], p2[0], 0x07060302u), __builtin_amdgcn_perm(p2[3], p2[2], 0x07060302u)};
+        const mu32x2 w3 = {__builtin_amdgcn_perm(p3[1], p3[0], 0x07060302u), __builtin_amdgcn_perm(p3[3], p3[2], 0x07060302u)};
+        *(mu32x2*)(base) = w1; *(mu32x2*)(base + PL6) = w2; *(mu32x2*)(base + 2 * PL6) = w3;
+    };
+    auto read_a6 = [&](int buf, int i, mbf16x8 (&f)[3]) __attribute__((always_inline)) {
+        const unsigned char* a = lds6 + buf * BUF6 + (wm0 + 16 * i + li) * P6 + 16 * lk;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) f[p] = *(const mbf16x8*)(a + p * PL6);
+    };
+    auto read_b6 = [&](int buf, mbf16x8 (&f)[X6 ? WN : 1][3]) __attribute__((always_inline)) {
+        const unsigned char* b = lds6 + buf * BUF6 + A6_PL + (wn0 + li) * P6 + 16 * lk;
+#pragma unroll
+        for (int j = 0; j < (X6 ? WN : 1); ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) f[j][p] = *(const mbf16x8*)(b + j * 16 * P6 + p * PL6);
+    };
+    // the 6 WN MFMAs of block row i; the column blocks alternate (a dependent MFMA is WN issues away); small terms first
+    auto mfma6 = [&](const mbf16x8 (&a)[3], const mbf16x8 (&b)[X6 ? WN : 1][3], f32x4 (&c)[WN]) __attribute__((always_inline)) {
+        if constexpr (X6) {
+#pragma unroll
+            for (int j = 0; j < WN; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[j][2], c[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[j][1], c[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[j][0], c[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[j][1], c[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[j][0], c[j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[j][0], c[j], 0, 0, 0);
+        }
+    };
+
     // this workgroup's range [g0, g1) of the chain's k-steps
     int nsteps[MAIN_MAX_SEG], total_steps = 0;
 #pragma unroll
@@ -207,11 +278,15 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[j], 1.44269504088896341f, -lse_c[i]));
                 }
+                if constexpr (X6) split_store6(v, lds6 + buf * BUF6 + (trow + RP * i) * P6 + 8 * quad);
+                else
                 *(f32x4*)(lds_a + buf * BML * P + (trow + RP * i) * P + 4 * quad) = v;       // (rows >= BM: spare LDS rows, never read)
             }
 #pragma unroll
             for (int i = 0; i < NB; ++i) {
                 if (i + NA < h0 || i + NA >= h1) continue;
+                if constexpr (X6) split_store6(vb[S][i], lds6 + buf * BUF6 + A6_PL + (trow + RP * i) * P6 + 8 * quad);
+                else
                 *(f32x4*)(lds_b + buf * BN * P + (trow + RP * i) * P + 4 * quad) = vb[S][i];
             }
         };
@@ -238,6 +313,49 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
             constexpr int PAR = decltype(par_c)::value;
             constexpr bool LAST = decltype(last_c)::value;
             typedef IntC<DEPTH == 2 ? (PAR ^ 1) : 0> SS;
+            if constexpr (X6) {
+                // sets alternate with the step's parity (three block rows per step): xa[PAR ^ 1] comes in holding block row 2 of the previous step
+                read_b6(PAR, xb[PAR]);
+                read_a6(PAR, 0, xa[PAR]);
+                mfma6(xa[PAR ^ 1], xb[PAR ^ 1], acc[2]);
+#pragma unroll
+                for (int q = 0; q < 6 * WN; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+                __builtin_amdgcn_sched_barrier(0);
+                if (LAST && NKIND >= 0 && pf_next) {
+                    const MainSeg& nx = args.seg[I + 1 < MAIN_MAX_SEG ? I + 1 : I];
+                    setup(IntC<NKIND>{}, nx);
+                    const int kn = nx.klen, nn = (kn + BK - 1) / BK;
+                    typedef std::integral_constant<bool, NKIND == MK_GATHER_MUL> NM;
+                    issue(S0{}, NM{}, kn, nn, 0);
+                    issue(S1{}, NM{}, kn, nn, 1);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    read_a6(PAR, i + 1, xa[PAR ^ 1 ^ i]);
+                    if (!LAST) {
+                        if (i == 0) stash(SS{}, Ff{}, PAR ^ 1, 0, (NA + NB) / 2);
+                        if (i == 1) { stash(SS{}, Ff{}, PAR ^ 1, (NA + NB) / 2, NA + NB); issue(SS{}, MULC{}, klen, nst, t + 1 + DEPTH); }
+                    }
+                    mfma6(xa[PAR ^ i], xb[PAR], acc[i]);
+#pragma unroll
+                    for (int q = 0; q < 6 * WN; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (LAST) {                              // nothing is carried over a segment switch: block row 2 now, zeros into the set the next segment's first step multiplies first
+                    mfma6(xa[PAR], xb[PAR], acc[2]);
+                    const mbf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) { xa[0][p] = z8; xa[1][p] = z8; }
+                }
+                __syncthreads();
+                return;
+            }
             read_frags(PAR, 0, afA, bfA);
             mfma(afB, bfB);                                              // (t-1, last sub-step): covers the reads above
 #pragma unroll
@@ -631,7 +749,7 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
     if constexpr (NSEG > 2) seg_pass(IntC<2>{});
     if constexpr (NSEG > 3) seg_pass(IntC<3>{});
     if constexpr (NSEG > 4) seg_pass(IntC<4>{});
-    mfma(afB, bfB);                                      // the last sub-step of the last segment
+    if constexpr (!X6) mfma(afB, bfB);                   // the last sub-step of the last segment (X6: every segment finishes its own last block row)
 
     // ---- epilogue: + Sh[r / K] (+ bias), ReLU, Dropout, store ---------------------------------------------------------
     // Every operand is fetched behind one uniform test per kind (a test per element puts each load in its own basic block:
@@ -793,6 +911,8 @@ static inline int launch_main_fwd(MainArgs& a, hipStream_t s) {
         }
         return NCX_E_FLAGS;
     }
+    if constexpr (CFG::X6) return NCX_E_FLAGS;       // (the X6 form exists for the fold sequences only)
+    else {
     if (a.dist_out) {                        // (in-kernel pairwise distance: whole k range in one workgroup, no slid windows in the v rows)
         if (a.split > 1 || a.nseg < 3 || a.seg[1].klen % MF_BK) return NCX_E_FLAGS;
         if (is({G, X, P, P, S})) return launch_main_fwd_seq<CFG, true, G, X, P, P, S>(a, s);
@@ -807,6 +927,7 @@ static inline int launch_main_fwd(MainArgs& a, hipStream_t s) {
     if (is({G, P, P, P}))    return launch_main_fwd_seq<CFG, false, G, P, P, P>(a, s);
     if (is({P, P}))          return launch_main_fwd_seq<CFG, false, P, P>(a, s);
     return NCX_E_FLAGS;
+    }
 }
 
 }  // namespace ncx

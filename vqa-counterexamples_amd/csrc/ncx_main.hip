@@ -10,6 +10,7 @@ typedef MainCfg<160, 128, 2, 2, 2, 1> MainCfgW;     // one workgroup per CU, 160
 typedef MainCfg<64, 64, 2, 2, 2, 3> MainCfg3;       // short chains (the answer-embedding gradient: 16 k-steps): three small workgroups per CU
 typedef MainCfg<48, 64, 1, 4, 2, 2> MainCfgFold;    // MK_VFOLD sequences: 48 x 64 tiles (two triplets), two workgroups per CU
 typedef MainCfg<96, 64, 2, 2, 2, 2> MainCfgFold4;   // MK_VFOLD sequences: 96 x 64 tiles (four triplets share the W_k | W_m tiles), two workgroups per CU
+typedef MainCfg<192, 64, 4, 2, 2, 2, 512, true> MainCfgFold8X6;   // ... with the segments after the fold on the bf16 matrix path, three-plane operands (NCX_F_X6)
 typedef MainCfg<192, 64, 4, 2, 2, 2, 512> MainCfgFold8;   // MK_VFOLD on 192 x 64 tiles: ONE 8-wave workgroup per CU, eight triplets share the W_k | W_m tiles (experiment: NCX_FOLD8)
 
 // Measured inside the training step at configs[1] (B = 512: 256 tiles of 96 x 128): 338 us with one 96 x 128 workgroup per CU,
@@ -26,6 +27,7 @@ int main_forward(MainArgs& a, hipStream_t s) {
         if (a.epi.rowdiv == 48 && rows == 48) rows = 96;                       // (K = 48 exists on the one-triplet-per-wave forms only)
         if (const char* f4 = hook_env("NCX_FOLD4")) rows = atoi(f4) != 0 ? 96 : (a.epi.rowdiv == 48 ? 96 : 48);
         if (const char* f8 = hook_env("NCX_FOLD8")) rows = atoi(f8) != 0 ? 192 : (rows == 192 ? 96 : rows);
+        if (rows == 192 && a.x6) return launch_main_fwd<MainCfgFold8X6>(a, s);
         return rows == 192 ? launch_main_fwd<MainCfgFold8>(a, s) : rows == 96 ? launch_main_fwd<MainCfgFold4>(a, s) : launch_main_fwd<MainCfgFold>(a, s);
     }
     long long T = 0;
