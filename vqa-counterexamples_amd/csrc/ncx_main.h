@@ -50,7 +50,9 @@ struct MainCfg {
     static constexpr int RP = T / 8;                                // tile rows per loader pass (8 threads x 16 bytes per 32-float row)
     static constexpr int BM_LDS = (BM + RP - 1) / RP * RP;        // A rows held in LDS (a multiple of the loader pass)
     static constexpr int LDS6 = 2 * 3 * (BM_LDS + BN) * MF6_P;      // X6: [2 buffers][3 planes][A rows | W rows][MF6_P]
-    static constexpr int LDS = X6_ && LDS6 > 2 * (BM_LDS + BN) * MF_P * 4 ? LDS6 : 2 * (BM_LDS + BN) * MF_P * 4;
+    static constexpr int LDS_FOLD6 = 2 * (3 * 208 * MF6_P + 8 * 32 * 4 + 128 * MF_P * 4);   // X6 fold: [2][three planes of 208 v_k rows | 8 v_o rows fp32 | W_k, W_m 128 rows fp32]
+    static constexpr int LDS32 = 2 * (BM_LDS + BN) * MF_P * 4;
+    static constexpr int LDS = !X6_ ? LDS32 : (LDS_FOLD6 > LDS6 ? (LDS_FOLD6 > LDS32 ? LDS_FOLD6 : LDS32) : (LDS6 > LDS32 ? LDS6 : LDS32));
     static constexpr int LDS_FOLD = BM % 96 == 0 ? 2 * (32 * (T / 64) + 128) * MF_P * 4   // MK_VFOLD, one triplet per wave: A 32 rows per wave, W_k | W_m 2 x 64 rows
                                                  : 2 * (80 + 2 * 64) * MF_P * 4;          // MK_VFOLD on 48-row tiles: A 80 rows, two effective weight tiles
 };
@@ -143,17 +145,6 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
     constexpr int P6 = MF6_P, A6_PL = BML * P6, PL6 = (BML + BN) * P6, BUF6 = 3 * PL6;
     unsigned char* const lds6 = (unsigned char*)mf_smem;
     mbf16x8 xa[2][3], xb[2][X6 ? WN : 1][3];             // [alternating set][plane]; [parity of the step][column block][plane]
-    if constexpr (X6) {
-        const mbf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                xa[q][p] = z8;
-#pragma unroll
-                for (int j = 0; j < WN; ++j) xb[q][j][p] = z8;
-            }
-    }
     auto split_store6 = [&](f32x4 v, unsigned char* base) __attribute__((always_inline)) {
         unsigned p1[4], p2[4], p3[4];
 #pragma unroll
@@ -715,6 +706,215 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
       }
     };
 
+    // ---- MK_VFOLD under X6 (192 x 64 tiles, K = 24: eight triplets, wave w = triplet w x all 64 columns) --------------------------------
+    // As run_vfold4, on the bf16 matrix path: the v_k rows are cut into three bf16 planes when they are stored to LDS (24 compact rows per
+    // triplet; a wave's second block row runs 8 rows into its neighbour's -- those outputs are dropped); W_k, W_m and v_o stay fp32 in LDS, and
+    // the effective-weight fragment of a column block is built per wave on the vector ALU,
+    //     b = fma(v_o[w][k], W_m[n][k], W_k[n][k])     (the expression of the fp32 forms)
+    // then cut into its three planes in registers: 8 fma + 44 split / pack operations per lane and column block, under the 12 MFMAs of the
+    // block before it.  The last column block's MFMAs of a step run after the barrier, over the first reads and the first build of the next.
+    auto run_vfold6 = [&](const MainSeg& sg, const bool pf_next) __attribute__((always_inline)) {
+      if constexpr (X6) {
+        constexpr int ARC = 208;                                   // A rows per plane: 192 + the 8 the last wave's second block row reads (+ 8 spare)
+        constexpr int A_PLX = ARC * P6, VO_OFF = 3 * A_PLX, W_OFF = VO_OFF + 8 * 32 * 4, BUFX = W_OFF + 128 * P * 4;
+        static_assert(2 * BUFX <= CFG::LDS, "fold tile (X6)");
+        static_assert(RP == 64, "fold loader (X6)");
+        const int klen = sg.klen, nst = klen / BK;
+        // loader items of thread (trow, quad): 0 .. 2 = v_k row trow + 64 i of the tile (triplet rho / 24, candidate rho % 24); 3 = v_o of triplet trow & 7
+        // (eight copies of each quad: every thread has one); 4 / 5 = row trow of W_k / W_m
+        gfptr pA[4], pB[2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) pA[i] = (gfptr)sg.a + (long long)((giptr)sg.idx)[min(m0 + trow + 64 * i, M - 1)] * sg.lda;
+        pA[3] = (gfptr)sg.a + (long long)((giptr)sg.idx2)[min(m0 + 24 * (trow & 7), M - 1)] * sg.lda;
+        {
+            const int n = min(n0 + trow, N - 1);
+            pB[0] = (gfptr)sg.b + (long long)n * sg.ldb; pB[1] = (gfptr)sg.b2 + (long long)n * sg.ldb;
+        }
+        f32x4 va4[2][4], vb4[2][2];
+        auto vissue = [&](auto set_c, int t) __attribute__((always_inline)) {
+            constexpr int SS_ = decltype(set_c)::value;
+            const int c = min(t, nst - 1) * BK + 4 * quad;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) va4[SS_][i] = *(gf4ptr)(pA[i] + c);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) vb4[SS_][i] = *(gf4ptr)(pB[i] + c);
+        };
+        auto split3 = [&](const float (&x)[4], unsigned (&w1)[2], unsigned (&w2)[2], unsigned (&w3)[2]) __attribute__((always_inline)) {
+            unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                p1[j] = __builtin_bit_cast(unsigned, x[j]) & 0xFFFF0000u;
+                const float r1 = x[j] - __builtin_bit_cast(float, p1[j]);
+                p2[j] = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+                const float r2 = r1 - __builtin_bit_cast(float, p2[j]);
+                p3[j] = __builtin_bit_cast(unsigned, r2);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                w1[h] = __builtin_amdgcn_perm(p1[2 * h + 1], p1[2 * h], 0x07060302u);
+                w2[h] = __builtin_amdgcn_perm(p2[2 * h + 1], p2[2 * h], 0x07060302u);
+                w3[h] = __builtin_amdgcn_perm(p3[2 * h + 1], p3[2 * h], 0x07060302u);
+            }
+        };
+        auto vstash = [&](auto set_c, int buf, int part) __attribute__((always_inline)) {      // part 0: v_k items 0, 1; part 1: v_k item 2 + v_o; part 2: W_k | W_m
+            constexpr int SS_ = decltype(set_c)::value;
+            unsigned char* const bb = lds6 + buf * BUFX;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                if ((i < 2) != (part == 0) || part == 2) continue;
+                const f32x4 v = va4[SS_][i];
+                const float x[4] = {v[0], v[1], v[2], v[3]};
+                unsigned w1[2], w2[2], w3[2];
+                split3(x, w1, w2, w3);
+                unsigned char* d = bb + (trow + 64 * i) * P6 + 8 * quad;
+                *(mu32x2*)(d) = mu32x2{w1[0], w1[1]}; *(mu32x2*)(d + A_PLX) = mu32x2{w2[0], w2[1]}; *(mu32x2*)(d + 2 * A_PLX) = mu32x2{w3[0], w3[1]};
+            }
+            if (part == 1) *(f32x4*)(bb + VO_OFF + ((trow & 7) * 32 + 4 * quad) * 4) = va4[SS_][3];
+            if (part == 2) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) *(f32x4*)(bb + W_OFF + ((trow + 64 * i) * P + 4 * quad) * 4) = vb4[SS_][i];
+            }
+        };
+        f32x4 acc4[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        struct Raw { f32x4 wk[2], wm[2]; };                          // W_k / W_m [n = 16 j + li][k = 8 lk .. 8 lk + 7] of one column block
+        const mbf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};
+        mbf16x8 af[2][2][3];                                        // [set][block row][plane]: A fragments of a step (set = parity of the step)
+        mbf16x8 bq[2][3];                                           // effective-weight planes of a column block, two in flight
+        f32x4 vo[2];                                                // v_o[w][8 lk .. 8 lk + 7]
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { af[1][0][p] = z8; af[1][1][p] = z8; bq[1][p] = z8; }
+        auto read_af = [&](int buf, mbf16x8 (&f)[2][3]) __attribute__((always_inline)) {
+            const unsigned char* a = lds6 + buf * BUFX + (24 * wave + li) * P6 + 16 * lk;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) f[i][p] = *(const mbf16x8*)(a + i * 16 * P6 + p * A_PLX);
+        };
+        auto read_vo = [&](int buf) __attribute__((always_inline)) {
+            const unsigned char* v = lds6 + buf * BUFX + VO_OFF + (wave * 32 + 8 * lk) * 4;
+            vo[0] = *(const f32x4*)(v); vo[1] = *(const f32x4*)(v + 16);
+        };
+        auto read_w = [&](int buf, int j, Raw& r) __attribute__((always_inline)) {
+            const unsigned char* b = lds6 + buf * BUFX + W_OFF + ((16 * j + li) * P + 8 * lk) * 4;
+            r.wk[0] = *(const f32x4*)(b); r.wk[1] = *(const f32x4*)(b + 16);
+            r.wm[0] = *(const f32x4*)(b + 64 * P * 4); r.wm[1] = *(const f32x4*)(b + 64 * P * 4 + 16);
+        };
+        auto build = [&](const Raw& r, mbf16x8 (&o)[3]) __attribute__((always_inline)) {
+            unsigned w1[4], w2[4], w3[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float x[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float v_ = vo[h][e], m_ = r.wm[h][e], k_ = r.wk[h][e]; x[e] = __builtin_fmaf(v_, m_, k_); }
+                unsigned a1[2], a2[2], a3[2];
+                split3(x, a1, a2, a3);
+                w1[2 * h] = a1[0]; w1[2 * h + 1] = a1[1]; w2[2 * h] = a2[0]; w2[2 * h + 1] = a2[1]; w3[2 * h] = a3[0]; w3[2 * h + 1] = a3[1];
+            }
+            typedef unsigned int mu32x4 __attribute__((ext_vector_type(4)));
+            o[0] = __builtin_bit_cast(mbf16x8, mu32x4{w1[0], w1[1], w1[2], w1[3]});
+            o[1] = __builtin_bit_cast(mbf16x8, mu32x4{w2[0], w2[1], w2[2], w2[3]});
+            o[2] = __builtin_bit_cast(mbf16x8, mu32x4{w3[0], w3[1], w3[2], w3[3]});
+        };
+        // the 12 MFMAs of column block j: the two block rows alternate; small terms first
+        auto fmfma = [&](const mbf16x8 (&a)[2][3], const mbf16x8 (&b)[3], int j) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[2], acc4[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[1], acc4[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][2], b[0], acc4[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[1], acc4[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][1], b[0], acc4[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][0], b[0], acc4[i][j], 0, 0, 0);
+        };
+        auto pin6 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        typedef IntC<0> V0; typedef IntC<1> V1;
+        vissue(V0{}, 0);
+        vissue(V1{}, 1);
+        vstash(V0{}, 0, 0); vstash(V0{}, 0, 1); vstash(V0{}, 0, 2);
+        vissue(V0{}, 2);
+        __syncthreads();
+        // step t (parity PAR): af[PAR ^ 1] / bq[1] come in holding the A fragments and column block 3 of step t - 1 (zeros at the start)
+        auto vstep = [&](auto par_c, auto last_c, int t) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(par_c)::value;
+            constexpr bool LAST = decltype(last_c)::value;
+            typedef IntC<PAR ^ 1> SS;
+            Raw r0, r1;
+            read_vo(PAR);
+            read_w(PAR, 0, r0);
+            read_af(PAR, af[PAR]);
+            read_w(PAR, 1, r1);
+            fmfma(af[PAR ^ 1], bq[1], 3);                                // (t - 1, column block 3)
+            build(r0, bq[0]);
+            pin6();
+            if (LAST && pf_next) {                                       // the next (plain) segment's first tiles
+                const MainSeg& nx = args.seg[1];
+                setup(IntC<K1 < 0 ? 0 : K1>{}, nx);
+                const int kn = nx.klen, nn = (kn + BK - 1) / BK;
+                issue(S0{}, Ff{}, kn, nn, 0);
+                issue(S1{}, Ff{}, kn, nn, 1);
+            }
+            // column block 0 under the build of 1, 1 under 2, 2 under 3
+            read_w(PAR, 2, r0);
+            if (!LAST) vstash(SS{}, PAR ^ 1, 0);
+            fmfma(af[PAR], bq[0], 0);
+            build(r1, bq[1]);
+            pin6();
+            read_w(PAR, 3, r1);
+            if (!LAST) vstash(SS{}, PAR ^ 1, 1);
+            fmfma(af[PAR], bq[1], 1);
+            build(r0, bq[0]);
+            pin6();
+            if (!LAST) { vstash(SS{}, PAR ^ 1, 2); vissue(SS{}, t + 3); }
+            fmfma(af[PAR], bq[0], 2);
+            build(r1, bq[1]);
+            pin6();
+            __syncthreads();
+        };
+        int t = 0;
+        for (; t + 2 < nst; t += 2) { vstep(V0{}, Ff{}, t); vstep(V1{}, Ff{}, t + 1); }
+        if (t + 1 < nst) { vstep(V0{}, Ff{}, t); vstep(V1{}, Tt{}, t + 1); fmfma(af[1], bq[1], 3); }
+        else { vstep(V0{}, Tt{}, t); fmfma(af[0], bq[1], 3); }
+        // padded (wave = triplet, 32 rows x 64 columns) -> compact (the 4 x 2 wave layout of the segments that follow), through LDS
+        constexpr int CP = 68;
+        float* const fc = mf_smem;                                       // [8 x 32 padded rows][CP]   (every fragment read is complete: last barrier)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) fc[(32 * wave + 16 * i + 4 * lk + q) * CP + 16 * j + li] = acc4[i][j][q];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int rho = wm0 + 16 * i + 4 * lk + q;               // compact tile row 0 .. 191 = triplet rho / 24, candidate rho % 24
+                    acc[i][j][q] = fc[(32 * (rho / 24) + rho % 24) * CP + wn0 + 16 * j + li];
+                }
+        __syncthreads();
+      }
+    };
+
     // segment I runs its steps [lo, hi) = [g0, g1) intersected with the segment; the first one that has any loads its own
     // first tiles, every later one finds them loaded by its predecessor's last step
     bool started = false;
@@ -738,7 +938,19 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
         stamp(1 + I);
     };
     if constexpr (VFOLD) {
-        if constexpr (BM % 96 == 0) run_vfold4(args.seg[0], NSEG > 1);
+        if constexpr (X6) {
+            run_vfold6(args.seg[0], NSEG > 1);
+            const mbf16x8 z8 = {0, 0, 0, 0, 0, 0, 0, 0};       // (here, not at the top: 72 registers of zeros would live through the fold)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    xa[q][p] = z8;
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) xb[q][j][p] = z8;
+                }
+        }
+        else if constexpr (BM % 96 == 0) run_vfold4(args.seg[0], NSEG > 1);
         else run_vfold(args.seg[0], NSEG > 1);
         base = nsteps[0]; started = true;
         stamp(1);

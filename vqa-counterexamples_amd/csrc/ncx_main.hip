@@ -27,7 +27,7 @@ int main_forward(MainArgs& a, hipStream_t s) {
         if (a.epi.rowdiv == 48 && rows == 48) rows = 96;                       // (K = 48 exists on the one-triplet-per-wave forms only)
         if (const char* f4 = hook_env("NCX_FOLD4")) rows = atoi(f4) != 0 ? 96 : (a.epi.rowdiv == 48 ? 96 : 48);
         if (const char* f8 = hook_env("NCX_FOLD8")) rows = atoi(f8) != 0 ? 192 : (rows == 192 ? 96 : rows);
-        if (rows == 192 && a.x6) return launch_main_fwd<MainCfgFold8X6>(a, s);
+        if (rows == 192 && a.x6 && a.epi.rowdiv == 24) return launch_main_fwd<MainCfgFold8X6>(a, s);      // (K = 24: a triplet per wave)
         return rows == 192 ? launch_main_fwd<MainCfgFold8>(a, s) : rows == 96 ? launch_main_fwd<MainCfgFold4>(a, s) : launch_main_fwd<MainCfgFold>(a, s);
     }
     long long T = 0;
