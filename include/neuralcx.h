@@ -65,12 +65,18 @@ extern "C" {
  * have run on the same workspace (its `dscores` may be NULL).  K <= 32 and H <= 256 only (ncx_train_tail says NCX_E_DIMS
  * otherwise: clear the bit and use the three calls). */
 #define NCX_F_FUSED_TAIL (1u << 6)
-/* Not the default (the headline path is fp32 MFMA): the row-reduction weight-gradient products of linear_1 that are not the per-triplet fold
- * (dGt and the z_other / dist|rank / shared-segment column blocks: csrc/ncx_dwtn.hip) take their fp32 operands as THREE bf16 planes each
- * (x = x1 + x2 + x3 exactly, by truncation) and run the six products that matter on the bf16 matrix path with fp32 accumulation: what is dropped
- * is 2^-24 relative, the rounding error of one fp32 operation ("bf16 x 6": fp32-grade, unlike the two-plane "bf16 x 3" form).
- * Results agree with the fp32 kernels to fp32 rounding, not bitwise (another summation order).  Ignored where the balanced TN launch does not run
- * (shapes outside dw_tn8_shapes_ok, B > 2048). */
+/* "bf16 x 6": fp32-grade arithmetic on the bf16 matrix path.  NOT the default -- the headline path is fp32 MFMA, and this bit is never set unless the
+ * caller sets it.  With it, the three big products of the training step take their fp32 operands as THREE bf16 planes each (x = x1 + x2 + x3
+ * EXACTLY: x1 = x & 0xFFFF0000, x2 = (x - x1) & 0xFFFF0000, x3 = x - x1 - x2, cut when a tile is stored to LDS) and run the six plane products
+ * that matter (a1 x1 + a1 x2 + a2 x1 + a1 x3 + a2 x2 + a3 x1) on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; products of bf16 values are
+ * exact in fp32, so what is dropped is 2^-24 relative: the rounding error of ONE fp32 operation (unlike the two-plane "bf16 x 3" form, whose
+ * 2^-16 error fails the suite's ReLU-kink conditioning: DESIGN 5d).  Covered:
+ *   - linear_1 forward on the 192-row form at K = 24 (per-triplet fold: the effective weight is formed in fp32, b = fma(v_o, W_m, W_k), then cut),
+ *   - d linear_1.weight[:, v_other | v_orig*v_other] (the per-triplet fold pass, H % 256 == 0 and dv % 64 == 0),
+ *   - dGt and every other column block of d linear_1.weight (the balanced TN launch, B <= 2048).
+ * Shapes outside fall back to the fp32 kernels silently (same results to rounding).  Results agree with the fp32 kernels to fp32 rounding, not
+ * bitwise (another summation order); every parity test of the suite passes at its unchanged tolerance with the bit set (NCX_X6=1 in the
+ * environment of the Python binding sets it for a whole process). */
 #define NCX_F_X6       (1u << 7)
 /* (v_emb / q_emb / z_emb lesions replace INPUTS by uniform noise: the host does that before the call) */
 

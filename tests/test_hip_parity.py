@@ -662,6 +662,7 @@ def test_forward_fold_forms_vs_oracle(K, fold4, H, monkeypatch):
     bit-identical (same expression, same k order).  B = 9 leaves the last 96-row tile ragged, H = 300 the last column tile (44 of 64).
     The 192-row form (eight waves, one workgroup per CU: what the planner takes at configs[1]) is forced the same way."""
     from neuralcx import ops
+    monkeypatch.setattr(ops, "EXTRA_FLAGS", 0)          # (bit-identity is a property of the three fp32 forms: under NCX_X6=1 the 192-row form is another kernel, test_x6_forward_192_row_form_vs_oracle)
     monkeypatch.setenv("NCX_EXPERIMENT", "1")
     monkeypatch.setenv("NCX_FOLD4", fold4)
     d = orc.Dims(K=K, dv=96 if H == 64 else 160, dq=64, dz=24, A=40, H=H, L=1)
@@ -719,6 +720,8 @@ def test_x6_runs_and_agrees_with_the_fp32_kernels_to_rounding(monkeypatch):
     _, _, g6 = run_hip(d, None, params, batch)
     differs = False
     for k in g32:                                    # (the forward's first layer runs on the split operands too: every gradient moves, by rounding)
+        if k == "out.bias":                          # zero in maths (the listwise loss is shift-invariant): rounding noise of 1e-9 on both sides
+            continue
         a, b = g32[k], g6[k]
         differs |= not np.array_equal(a, b)
         assert np.abs(a - b).max() <= 1e-5 * max(np.abs(a).max(), 1e-30), (k, np.abs(a - b).max(), np.abs(a).max())

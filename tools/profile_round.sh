@@ -3,6 +3,7 @@
 #   c2 (BASELINE configs[1], the headline): tools/profile_round.sh r4_01 c2
 #   c3 (configs[2], + fused MUTAN producer): tools/profile_round.sh r4_c3 c3 --c3
 #   c5 (configs[4], K=48 B=1024 bf16):       tools/profile_round.sh r4_c5 c5 --bf16 --K 48 --batch 1024
+#   x6 (configs[1] under NCX_F_X6):          tools/profile_round.sh r4_x6 x6 --x6
 # kernel trace + stats of the bench, then the PMC passes the MI355X guide prescribes (separate runs, --kernel-trace only).
 set -e
 TAG=${1:-r4}; KEY=${2:-c2}

@@ -720,22 +720,26 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
         static_assert(2 * BUFX <= CFG::LDS, "fold tile (X6)");
         static_assert(RP == 64, "fold loader (X6)");
         const int klen = sg.klen, nst = klen / BK;
-        // loader items of thread (trow, quad): 0 .. 2 = v_k row trow + 64 i of the tile (triplet rho / 24, candidate rho % 24); 3 = v_o of triplet trow & 7
-        // (eight copies of each quad: every thread has one); 4 / 5 = row trow of W_k / W_m
-        gfptr pA[4], pB[2];
+        // loader items of thread (trow, quad): 0 .. 2 = v_k row trow + 64 i of the tile (triplet rho / 24, candidate rho % 24); ONE float of v_o (triplet
+        // (tid >> 5) & 7, column tid & 31: the 8 x 32 floats of the step twice over -- 2 KB of returning loads instead of the 8 KB of a quad per thread);
+        // 4 / 5 = row trow of W_k / W_m
+        gfptr pA[3], pB[2];
 #pragma unroll
         for (int i = 0; i < 3; ++i) pA[i] = (gfptr)sg.a + (long long)((giptr)sg.idx)[min(m0 + trow + 64 * i, M - 1)] * sg.lda;
-        pA[3] = (gfptr)sg.a + (long long)((giptr)sg.idx2)[min(m0 + 24 * (trow & 7), M - 1)] * sg.lda;
+        const int vo_t = (tid >> 5) & 7, vo_c = tid & 31;
+        const gfptr pV = (gfptr)sg.a + (long long)((giptr)sg.idx2)[min(m0 + 24 * vo_t, M - 1)] * sg.lda + vo_c;
         {
             const int n = min(n0 + trow, N - 1);
             pB[0] = (gfptr)sg.b + (long long)n * sg.ldb; pB[1] = (gfptr)sg.b2 + (long long)n * sg.ldb;
         }
-        f32x4 va4[2][4], vb4[2][2];
+        f32x4 va4[2][3], vb4[2][2];
+        float vv[2];
         auto vissue = [&](auto set_c, int t) __attribute__((always_inline)) {
             constexpr int SS_ = decltype(set_c)::value;
             const int c = min(t, nst - 1) * BK + 4 * quad;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) va4[SS_][i] = *(gf4ptr)(pA[i] + c);
+            for (int i = 0; i < 3; ++i) va4[SS_][i] = *(gf4ptr)(pA[i] + c);
+            vv[SS_] = pV[min(t, nst - 1) * BK];
 #pragma unroll
             for (int i = 0; i < 2; ++i) vb4[SS_][i] = *(gf4ptr)(pB[i] + c);
         };
@@ -769,7 +773,7 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
                 unsigned char* d = bb + (trow + 64 * i) * P6 + 8 * quad;
                 *(mu32x2*)(d) = mu32x2{w1[0], w1[1]}; *(mu32x2*)(d + A_PLX) = mu32x2{w2[0], w2[1]}; *(mu32x2*)(d + 2 * A_PLX) = mu32x2{w3[0], w3[1]};
             }
-            if (part == 1) *(f32x4*)(bb + VO_OFF + ((trow & 7) * 32 + 4 * quad) * 4) = va4[SS_][3];
+            if (part == 1) *(float*)(bb + VO_OFF + (vo_t * 32 + vo_c) * 4) = vv[SS_];
             if (part == 2) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) *(f32x4*)(bb + W_OFF + ((trow + 64 * i) * P + 4 * quad) * 4) = vb4[SS_][i];
