@@ -768,3 +768,18 @@ def test_x6_forward_192_row_form_vs_oracle(K, H, monkeypatch, x6):
 
 def test_x6_configs1_unconditioned_logits_vs_oracle(x6):
     test_configs1_unconditioned_logits_vs_oracle()
+
+
+@pytest.mark.parametrize("B,K,H,L,dv", [(1, 24, 256, 1, 64), (7, 24, 256, 2, 128), (13, 48, 256, 1, 192), (37, 24, 512, 1, 64)])
+def test_fused_v_gradient_8_wave_form_vs_oracle(B, K, H, L, dv, monkeypatch):
+    """k_dw_km8 (the per-triplet fold pass as one 8-wave workgroup per CU on 256 x 64 tile pairs, fp32 MFMA: what shapes with H a multiple of
+    256 and dv a multiple of 64 take) on forced small shapes: chunks of one triplet, empty chunks, an odd number of reduction steps per chunk,
+    K = 48 (two 24-row steps per triplet), two row tiles.  (k_dw_km keeps every other shape: test_fused_v_gradient_kernel_vs_oracle.)"""
+    from neuralcx import ops
+    monkeypatch.setattr(ops, "EXTRA_FLAGS", 0)
+    monkeypatch.setenv("NCX_EXPERIMENT", "1")
+    monkeypatch.setenv("NCX_KM_FORCE", "1")
+    d = orc.Dims(K=K, dv=dv, dq=50, dz=18, A=45, H=H, L=L)
+    params = orc.init_params(d, seed=23 + B, gain=3.0)
+    batch = random_case(700 + B, B, d)
+    compare_with_oracle(d, None, params, batch)

@@ -243,6 +243,170 @@ __global__ __launch_bounds__(T, OCC) void k_dw_km(const float* __restrict__ dpre
 }
 
 
+// ---- the same pass as ONE 8-wave workgroup per CU on a 256 (all of H) x 64 tile pair, in the style of k_dw_tn8 (round 4) -------------------------
+// What the balanced TN kernel taught (ncx_dwtn.hip): all of H per workgroup (a dpre row is fetched and stored to LDS once per 64 columns, not twice),
+// the interleaved block mapping (one ds_read_b128 / ds_read_b64 feeds four / two MFMA blocks: 4 LDS reads per 16 MFMAs where k_dw_km issues one
+// ds_read_b32 per operand), a rotated loop (the last sub-step's MFMAs after the barrier).  A reduction step is a 24-row triplet part = THREE 8-deep
+// sub-steps; T_b accumulates from an inline-zero C operand into one of two scratch accumulators (by the step's parity) and is folded into both outputs
+// under the MFMAs of the next step.  Same k-chunks and slab layout as k_dw_km (its reduction follows unchanged); the summation order inside a
+// triplet differs from k_dw_km's, so the two kernels agree to fp32 rounding, not bitwise.
+// (Tried: two reduction steps per LDS buffer = 96 MFMAs per wave between barriers, one register set re-requested item by item: 118 spilled
+// registers, 0.556 ms for DW1C -- dropped.)
+constexpr int KM8_PA = 256, KM8_PB = 80;                            // LDS pitches (floats), as k_dw_tn8
+constexpr int KM8_LDS = 2 * (24 * KM8_PA + 32 * KM8_PB) * 4;
+
+__global__ __launch_bounds__(512, 1) void k_dw_km8(const float* __restrict__ dpre, int H, const float* __restrict__ feats, int dv,
+                                                   const int* __restrict__ idx_k, const int* __restrict__ idx_o, int B, int Kc,
+                                                   int chunk, int tiles_m, int S, float* __restrict__ slab) {
+    constexpr int T = 512, BM = 256, BN = 64, K = 24, PA = KM8_PA, PB = KM8_PB, NA = 3;
+    constexpr int A_EL = K * PA, B_EL = 32 * PB;
+    extern __shared__ __attribute__((aligned(16))) float km8_smem[];
+    float* const lds_a = km8_smem;                     // [2][24][PA]
+    float* const lds_b = km8_smem + 2 * A_EL;          // [2][32][PB]   rows 0 .. 23: v_k of the step's rows; rows 24 .. 31: the triplet's v_o (eight copies)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int wm0 = 64 * (wave >> 1), wn0 = 32 * (wave & 1);
+    const int z = blockIdx.x % S, t = blockIdx.x / S;
+    const int tm = t % tiles_m, tn = t / tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int spt = Kc / K;
+    const int t0 = z * chunk, t1 = min(t0 + chunk, B);
+    if (t0 >= B) return;
+    const int b0 = t0 * spt, b1 = t1 * spt;
+
+    f32x4 acc_k[4][2], acc_m[4][2], tt[2][4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            acc_k[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc_m[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            tt[0][i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; tt[1][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    const int arow = tid >> 6, aq = tid & 63;
+    const int brow = tid >> 4, bq = tid & 15;
+    typedef const __attribute__((address_space(1))) float* gfp;
+    typedef const __attribute__((address_space(1))) f32x4u* gf4p;
+    typedef const __attribute__((address_space(1))) int* gip;
+    f32x4 va[2][NA], vb[2];
+    auto load_idx = [&](int b) __attribute__((always_inline)) -> int {
+        const long long r0 = (long long)min(b, b1 - 1) * K;
+        return brow < K ? ((gip)idx_k)[r0 + brow] : ((gip)idx_o)[r0];
+    };
+    int ixn = load_idx(b0);                                        // gather row of the NEXT issue (requested one issue ahead)
+    auto issue = [&](auto set_c, int b) __attribute__((always_inline)) {
+        constexpr int SS_ = decltype(set_c)::value;
+        const long long r0 = (long long)min(b, b1 - 1) * K;
+        const gfp ap = (gfp)dpre + (r0 + arow) * H + m0 + 4 * aq;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) va[SS_][i] = *(gf4p)(ap + (long long)(8 * i) * H);
+        vb[SS_] = *(gf4p)((gfp)feats + (long long)ixn * dv + n0 + 4 * bq);
+        ixn = load_idx(b + 1);
+    };
+    auto stash = [&](auto set_c, int buf, int h0, int h1) __attribute__((always_inline)) {
+        constexpr int SS_ = decltype(set_c)::value;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (i < h0 || i >= h1) continue;
+            *(f32x4*)(lds_a + buf * A_EL + (arow + 8 * i) * PA + 4 * aq) = va[SS_][i];
+        }
+        if (NA >= h0 && NA < h1) *(f32x4*)(lds_b + buf * B_EL + brow * PB + 4 * bq) = vb[SS_];
+    };
+    // fragment sets alternate with the step's parity (three sub-steps per step): F[PAR ^ 1] comes in holding sub-step 2 of the previous step
+    f32x4 fa[2][2]; f32x2 fb[2][2];                    // [set][e]
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { fa[q][e] = f32x4{0.f, 0.f, 0.f, 0.f}; fb[q][e] = f32x2{0.f, 0.f}; }
+    f32x2 vo[2] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};   // [parity of the step]: v_o of the lane's two columns
+    // interleaved block mapping: block (i, j) of a wave owns tile rows wm0 + 4 r + i, columns wn0 + 2 c + j; k order: MFMA (s, e) takes k = 8 s + 2 lk + e
+    auto read_frags = [&](int buf, int s, f32x4 (&af)[2], f32x2 (&bf)[2]) __attribute__((always_inline)) {
+        const int kk = 8 * s + 2 * lk;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            af[e] = *(const f32x4*)(lds_a + buf * A_EL + (kk + e) * PA + wm0 + 4 * li);
+            bf[e] = *(const f32x2*)(lds_b + buf * B_EL + (kk + e) * PB + wn0 + 2 * li);
+        }
+    };
+    auto mfma = [&](const f32x4 (&af)[2], const f32x2 (&bf)[2], f32x4 (&c)[4][2], auto first_c) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_c)::value;           // the step's first sub-step: e = 0 starts from zero
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    c[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e][i], bf[e][j], (FIRST && e == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : c[i][j], 0, 0, 0);
+    };
+    auto fold = [&](int i0, int i1, const f32x4 (&c)[4][2], const f32x2& v) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i < i0 || i >= i1) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc_k[i][j][q] += c[i][j][q];
+                    acc_m[i][j][q] = __builtin_fmaf(c[i][j][q], v[j], acc_m[i][j][q]);
+                }
+        }
+    };
+    auto pin = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    typedef std::integral_constant<int, 0> S0; typedef std::integral_constant<int, 1> S1;
+    typedef std::true_type Tt; typedef std::false_type Ff;
+    issue(S0{}, b0);
+    issue(S1{}, b0 + 1);
+    stash(S0{}, 0, 0, NA + 1);
+    issue(S0{}, b0 + 2);
+    __syncthreads();
+    auto step = [&](auto par_c, int b) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_c)::value;
+        typedef std::integral_constant<int, PAR ^ 1> SS;
+        // sub-step 2 of the previous step (zeros at the start) completes its T over the first reads of this buffer
+        read_frags(PAR, 0, fa[PAR], fb[PAR]);
+        vo[PAR] = *(const f32x2*)(lds_b + PAR * B_EL + K * PB + wn0 + 2 * li);
+        mfma(fa[PAR ^ 1], fb[PAR ^ 1], tt[PAR ^ 1], Ff{});
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(PAR, 1, fa[PAR ^ 1], fb[PAR ^ 1]);
+        stash(SS{}, PAR ^ 1, 0, 2);
+        mfma(fa[PAR], fb[PAR], tt[PAR], Tt{});
+        fold(0, 2, tt[PAR ^ 1], vo[PAR ^ 1]);
+        pin();
+        read_frags(PAR, 2, fa[PAR], fb[PAR]);
+        stash(SS{}, PAR ^ 1, 2, NA + 1);
+        issue(SS{}, b + 3);
+        mfma(fa[PAR ^ 1], fb[PAR ^ 1], tt[PAR], Ff{});
+        fold(2, 4, tt[PAR ^ 1], vo[PAR ^ 1]);
+        pin();
+        __syncthreads();
+    };
+    int b = b0;
+    for (; b + 1 < b1; b += 2) { step(S0{}, b); step(S1{}, b + 1); }
+    if (b < b1) { step(S0{}, b); mfma(fa[0], fb[0], tt[0], Ff{}); fold(0, 4, tt[0], vo[0]); }
+    else { mfma(fa[1], fb[1], tt[1], Ff{}); fold(0, 4, tt[1], vo[1]); }
+    float* dk = slab + ((long long)z * 2 + 0) * H * dv;
+    float* dm = slab + ((long long)z * 2 + 1) * H * dv;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const long long m = m0 + wm0 + 4 * (4 * lk + rg) + i;
+            const int n = n0 + wn0 + 2 * li;
+            *(f32x2*)(dk + m * dv + n) = f32x2{acc_k[i][0][rg], acc_k[i][1][rg]};
+            *(f32x2*)(dm + m * dv + n) = f32x2{acc_m[i][0][rg], acc_m[i][1][rg]};
+        }
+}
+
 // ---- the same pass on the bf16 matrix path with fp32-grade operands (NCX_F_X6; not the default) -------------------------------------------
 // Operands as in k_dw_tn8_x6 (ncx_dwtn.hip): every fp32 element is cut into three bf16 values by truncation when it is stored to LDS
 // (x = x1 + x2 + x3 exactly), six products per block on v_mfma_f32_16x16x32_bf16 with fp32 accumulation.  One 8-wave workgroup per CU on a
@@ -524,7 +688,16 @@ int dw_km(const ncx_dims& d, const float* dpre, const float* feats, const int* i
     int chunk;
     const int S = km_chunks(d, chunk);
     constexpr int R = 24;
-    if ((d.flags & NCX_F_X6) && d.H % 256 == 0 && d.dv % 64 == 0 && !hook_env("NCX_NO_X6") && !hook_env("NCX_NO_KM_X6")) {      // (K % 24 == 0: dw_km_supported)
+    // the 8-wave 256 x 64 form where the shape has whole tiles (configs[1] on one box: DW1C 0.2962-0.2970 ms against 0.3048, step 0.8465-0.8478 ms against 0.8578)
+    const bool x6 = (d.flags & NCX_F_X6) && !hook_env("NCX_NO_X6") && !hook_env("NCX_NO_KM_X6");
+    if (d.H % 256 == 0 && d.dv % 64 == 0 && !x6 && !hook_env("NCX_NO_KM8") && !hook_env("NCX_KM_BM") && !hook_env("NCX_KM_T") && !hook_env("NCX_KM_ABL")) {
+        static DevMask attr8{0};
+        NCX_HIP_TRY(set_max_lds_once(attr8, (const void*)k_dw_km8, KM8_LDS));
+        hipLaunchKernelGGL(k_dw_km8, dim3((d.H / 256) * (d.dv / 64) * S), dim3(512), KM8_LDS, s, dpre, d.H, feats, d.dv, idx_k, idx_o, d.B, d.K, chunk, d.H / 256, S, slab);
+        NCX_HIP_TRY(hipGetLastError());
+        return finish ? dw_km_finish(d, slab, g_vother, g_vmult, din, nullptr, 0, s) : NCX_OK;
+    }
+    if (x6 && d.H % 256 == 0 && d.dv % 64 == 0) {      // (K % 24 == 0: dw_km_supported)
         static DevMask attr6{0};
         NCX_HIP_TRY(set_max_lds_once(attr6, (const void*)k_dw_km_x6, KM6_LDS));
         hipLaunchKernelGGL(k_dw_km_x6, dim3((d.H / 256) * (d.dv / 64) * S), dim3(512), KM6_LDS, s, dpre, d.H, feats, d.dv, idx_k, idx_o, d.B, d.K, chunk, d.H / 256, S, slab);
