@@ -374,8 +374,8 @@ def main():
         names = {"MAIN": "k_main_fwd (csrc/ncx_main.h): linear_1 forward, the candidate segments chained into one fp32-MFMA accumulator "
                          "(v_other and v_orig*v_other as one per-triplet fold where the plan says so), Sh / ReLU / Dropout epilogue; tile: %s"
                          % plans["MAIN"]["tile"],
-                 "DW1C": "linear_1 weight gradient (all columns + dGt): k_dw_km (v_other + v_mult columns in one MFMA pass, per-triplet "
-                         "fold, 8 k-chunks) + k_dw_tn8 (dGt and every other column block: one balanced launch of 8-wave workgroups on 256 x 64 "
+                 "DW1C": "linear_1 weight gradient (all columns + dGt): k_dw_km8 (v_other + v_mult columns in one MFMA pass, per-triplet "
+                         "fold, 8 k-chunks, one 8-wave workgroup per CU on 256 x 64 tile pairs; other shapes: k_dw_km) + k_dw_tn8 (dGt and every other column block: one balanced launch of 8-wave workgroups on 256 x 64 "
                          "tiles; shapes it does not cover: seg_gemm TN %s grouped) + their merged fixed-order reduction"
                          % plans["DW1C"]["tile"]}
         peak = PEAK_F32_MFMA_TFLOPS

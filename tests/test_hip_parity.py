@@ -783,3 +783,28 @@ def test_fused_v_gradient_8_wave_form_vs_oracle(B, K, H, L, dv, monkeypatch):
     params = orc.init_params(d, seed=23 + B, gain=3.0)
     batch = random_case(700 + B, B, d)
     compare_with_oracle(d, None, params, batch)
+
+
+@pytest.mark.parametrize("H", [64, 300])
+@pytest.mark.parametrize("form", ["96", "192"])
+def test_distance_inside_the_fold_forms_vs_oracle(form, H, monkeypatch):
+    """The one-triplet-per-wave fold forms (96 / 192-row tiles, K = 24) can compute the pairwise distance ||v_o - v_k + 1e-6|| (cx.py:300) while they
+    stream the rows (k_prep then skips the feature rows; experiment hook NCX_DIST_IN_FOLD -- measured a wash at configs[1], so not the default): forced
+    at a small ragged size, logits, loss and every gradient -- d linear_1.weight[:, dist] reads the distance the forward kernel stored -- against the
+    oracle; and against the same form with k_prep's distance (equal to rounding)."""
+    from neuralcx import ops
+    monkeypatch.setattr(ops, "EXTRA_FLAGS", 0)
+    monkeypatch.setenv("NCX_EXPERIMENT", "1")
+    monkeypatch.setenv("NCX_FOLD4", "1")
+    monkeypatch.setenv("NCX_FOLD8", "1" if form == "192" else "0")
+    monkeypatch.setenv("NCX_DIST_IN_FOLD", "1")
+    d = orc.Dims(K=24, dv=96 if H == 64 else 160, dq=64, dz=24, A=40, H=H, L=1)
+    params = orc.init_params(d, seed=5, gain=3.0)
+    batch = random_case(78, 9, d)
+    s_in, _, g_in = compare_with_oracle(d, None, params, batch)
+    monkeypatch.delenv("NCX_DIST_IN_FOLD")
+    s_prep, _, g_prep = compare_with_oracle(d, None, params, batch)
+    assert not torch.equal(s_in, s_prep)                # (the hook really switched the source of the distance)
+    assert (s_in - s_prep).abs().max() <= 2e-6 * max(1.0, float(s_prep.abs().max()))
+    a, b = g_in["linear_1.weight"], g_prep["linear_1.weight"]
+    assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max()

@@ -52,7 +52,7 @@ if bf16:
 else:
     out["MAIN"] = total([part(("k_main_fwd", "MainCfg<96, 64")) or part(("k_main_fwd",))])
     # round 4: the fold kernel + the balanced 8-wave TN launch (ncx_dwtn.hip) + their merged reduction; earlier builds: the grouped TN GEMM
-    out["DW1C"] = total([part(("k_dw_km_x6",)) or part(("k_dw_km<",)), part(("k_dw_tn8",)) or part(("seg_gemm_kernel<128, 64, false, false",)),
+    out["DW1C"] = total([part(("k_dw_km_x6",)) or part(("k_dw_km8",)) or part(("k_dw_km<",)), part(("k_dw_tn8",)) or part(("seg_gemm_kernel<128, 64, false, false",)),
                          part(("k_dw_reduce_km_tn8",)) or part(("k_dw_km_reduce_fixup",))])
 for name, pat in (("k_prep", ("k_prep",)), ("k_adam", ("k_adam",))):
     p = part(pat)

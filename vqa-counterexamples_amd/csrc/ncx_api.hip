@@ -1234,8 +1234,13 @@ static int forward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_para
                        main_split(M, H, main_T) == 1 && !hook_env("NCX_NO_VFOLD");
     // Measured at configs[1]: inside the plain chain the distance costs the kernel 12 us and saves k_prep 30; inside the fold's
     // 48 x 64 tiles (a quarter of the MFMA work per vector instruction) it costs 31 us: there k_prep keeps computing it.
+    // Round 4, measured again for the one-triplet-per-wave fold forms (96 / 192-row tiles, K = 24: a wave's loader holds v_o beside every v_k quad it loads,
+    // the distance is ~14 vector operations per loaded quad and k_prep stops reading the feature rows): the fold loop goes from 5 085 to 5 790 cycles per k-step
+    // (5 740 with the arithmetic spread over the sub-steps) -- vector instructions are not free under fp32 MFMAs, each costs the matrix pipe ~8-15 cycles --
+    // so the kernel loses the 17 us k_prep gains (0.2938 against 0.2771 ms; step 0.8443 / 0.8483 against 0.8489).  Kept behind the hook NCX_DIST_IN_FOLD.
+    const bool dist_in_fold = vfold && d.K == 24 && main_fold_rows_eff(M, H, d.K) >= 96 && !(d.flags & NCX_F_X6) && hook_env("NCX_DIST_IN_FOLD");
     const bool dist_in_main = main_fwd_dims_ok(d) && (d.flags & NCX_F_V_DIST) && (d.flags & NCX_F_V_MULT) && d.dv % 32 == 0 &&
-                              main_split(M, H, main_T) == 1 && !vfold && !(hook_env("NCX_NO_DIST_IN_MAIN"));
+                              main_split(M, H, main_T) == 1 && (!vfold || dist_in_fold) && !(hook_env("NCX_NO_DIST_IN_MAIN"));
     ncx_dims dprep = d;
     if (dist_in_main) dprep.flags |= NCX_F_PRIV_DIST_IN_MAIN;
     if (!do_rest) pk.n = 0;                                   // prelude: no weight is read

@@ -296,10 +296,13 @@ __global__ __launch_bounds__(512, 1) void k_dw_km8(const float* __restrict__ dpr
         constexpr int SS_ = decltype(set_c)::value;
         const long long r0 = (long long)min(b, b1 - 1) * K;
         const gfp ap = (gfp)dpre + (r0 + arow) * H + m0 + 4 * aq;
+        // (the index request goes out FIRST: it is the load the next issue needs soonest, and vmcnt counts in order -- as the youngest load of the
+        // issue it made the next issue wait for every quad of this one)
+        const int ix = ixn;
+        ixn = load_idx(b + 1);
 #pragma unroll
         for (int i = 0; i < NA; ++i) va[SS_][i] = *(gf4p)(ap + (long long)(8 * i) * H);
-        vb[SS_] = *(gf4p)((gfp)feats + (long long)ixn * dv + n0 + 4 * bq);
-        ixn = load_idx(b + 1);
+        vb[SS_] = *(gf4p)((gfp)feats + (long long)ix * dv + n0 + 4 * bq);
     };
     auto stash = [&](auto set_c, int buf, int h0, int h1) __attribute__((always_inline)) {
         constexpr int SS_ = decltype(set_c)::value;
@@ -467,10 +470,13 @@ __global__ __launch_bounds__(512, 1) void k_dw_km_x6(const float* __restrict__ d
         constexpr int SS_ = decltype(set_c)::value;
         const long long r0 = (long long)min(b, b1 - 1) * K;
         const gfp ap = (gfp)dpre + (r0 + arow) * H + m0 + 4 * aq;
+        // (the index request goes out FIRST: it is the load the next issue needs soonest, and vmcnt counts in order -- as the youngest load of the
+        // issue it made the next issue wait for every quad of this one)
+        const int ix = ixn;
+        ixn = load_idx(b + 1);
 #pragma unroll
         for (int i = 0; i < NA; ++i) va[SS_][i] = *(gf4p)(ap + (long long)(8 * i) * H);
-        vb[SS_] = *(gf4p)((gfp)feats + (long long)ixn * dv + n0 + 4 * bq);
-        ixn = load_idx(b + 1);
+        vb[SS_] = *(gf4p)((gfp)feats + (long long)ix * dv + n0 + 4 * bq);
     };
     auto split_store = [&](f32x4 v, unsigned char* base) __attribute__((always_inline)) {
         unsigned p1[4], p2[4], p3[4];

@@ -106,6 +106,7 @@ int main_forward(MainArgs& a, hipStream_t s);
 // k-split of a problem for the fused forward kernel (48 x 128 tiles): 1 when its tiles already give every CU a workgroup,
 // else as many k-chunks as keep all workgroups resident at once (two per CU), at least 8 k-steps each.  T: k-steps of the whole chain.
 int main_split(long long M, long long N, long long T);
+int main_fold_rows_eff(long long M, long long N, int rowdiv);   // ... the form main_forward takes (hooks, K = 48 rule)
 int main_fold_rows(long long M, long long N);      // tile rows of the per-triplet fold: 192 (one 8-wave workgroup per CU), 96 (four triplets per workgroup) or 48
 
 // ncx_dwkm.hip: d linear_1.weight[:, v_other] and [:, v_mult] in one MFMA pass with a per-triplet fold

@@ -67,8 +67,9 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
     constexpr int DIST_SEG = VFOLD ? 1 : 2;              // the (dist | rank) segment: right after the one that streams v_o and v_k
     static_assert(!DIST || (VFOLD ? K1 == MK_PLAIN : (K1 == MK_GATHER_MUL && K2 == MK_PLAIN)), "DIST: v_o, v_k segment followed by the dist | rank segment");
     static_assert(!VFOLD || (CFG::BM == 48 && CFG::BN == 64 && CFG::WGM == 1 && CFG::WGN == 4 && CFG::DEPTH == 2) ||
-                            (CFG::BM == 96 && CFG::BN == 64 && CFG::WGM == 2 && CFG::WGN == 2 && CFG::DEPTH == 2 && !DIST) ||
-                            (CFG::BM == 192 && CFG::BN == 64 && CFG::T == 512 && CFG::WGM == 4 && CFG::WGN == 2 && CFG::DEPTH == 2 && !DIST), "fold: 48 x 64, 96 x 64 or (8 waves) 192 x 64 tiles");
+                            (CFG::BM == 96 && CFG::BN == 64 && CFG::WGM == 2 && CFG::WGN == 2 && CFG::DEPTH == 2) ||
+                            (CFG::BM == 192 && CFG::BN == 64 && CFG::T == 512 && CFG::WGM == 4 && CFG::WGN == 2 && CFG::DEPTH == 2), "fold: 48 x 64, 96 x 64 or (8 waves) 192 x 64 tiles");
+    static_assert(!(DIST && CFG::X6), "the X6 form leaves the distance to k_prep");
     constexpr int KS[6] = {K0, K1, K2, K3, K4, -1};
     constexpr int NSEG = K1 < 0 ? 1 : K2 < 0 ? 2 : K3 < 0 ? 3 : K4 < 0 ? 4 : 5;
     constexpr int BM = CFG::BM, BN = CFG::BN, BK = MF_BK, P = MF_P, DEPTH = CFG::DEPTH, BML = CFG::BM_LDS;
@@ -201,6 +202,8 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
     f32x4 va[DEPTH][NA], vm[DEPTH][NA], vb[DEPTH][NB];
     gfptr pa[NA]; gfptr pm[NA]; gfptr pb[NB]; float lse[NA];
     float dacc[NA];                                      // DIST: sum (v_o - v_k + 1e-6)^2 over this thread's column quads, per A row
+    // (one-triplet-per-wave fold forms: the finished distances of the tile's rows wait here, behind the LDS of the segments that follow and of the layout conversion)
+    constexpr int FOLD_DIST_OFF = 2 * (BML + BN) * P > 32 * (MT / 64) * 68 ? 2 * (BML + BN) * P : 32 * (MT / 64) * 68;
 #pragma unroll
     for (int i = 0; i < NA; ++i) dacc[i] = 0.f;
     auto setup = [&](auto kind_c, const MainSeg& g) __attribute__((always_inline)) {
@@ -285,9 +288,13 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
         if constexpr (DIST && I == DIST_SEG) {                  // the 8 threads of a row hold its partial sums: reduce, sqrt, keep, store
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
+                if constexpr (VFOLD && BM % 96 == 0) {
+                    dacc[i] = mf_smem[FOLD_DIST_OFF + min(trow + RP * i, BM - 1)];      // finished by run_vfold4 (another thread layout): through LDS
+                } else {
                 float d2 = dacc[i];
                 d2 += __shfl_xor(d2, 1, 64); d2 += __shfl_xor(d2, 2, 64); d2 += __shfl_xor(d2, 4, 64);
                 dacc[i] = sqrtf(d2);
+                }
                 const int r = m0 + trow + RP * i;
                 if (quad == 0 && tn == 0 && trow + RP * i < BM && r < M) args.dist_out[(long long)r * args.ld_dist] = dacc[i];
             }
@@ -571,9 +578,12 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
         // v_o, 15 spare) -- 4 MFMA row blocks per 48 rows against the 6 of the two plain segments, like 4 per 24 against 2 x 3
         const int kr = args.epi.rowdiv, blk = kr == 24 ? 32 : 64;
         gfptr pA[NAI], pB[NBI];
+        // loader item i of this thread: A row 32 wave + (lane >> 3) + 8 i -- a wave loads the rows of ITS 32-row block, so at K = 24 item 3 (block rows 24 ..
+        // 31: v_o, every one of them) gives every lane the v_o quad of the columns its v_k items cover: the pairwise distance needs no exchange
+        const int arow4 = 32 * wave + (lane >> 3);
 #pragma unroll
-        for (int i = 0; i < NAI; ++i) {                     // loader item i of this thread: A row trow + RP i
-            const int lr = trow + RP * i, tr = lr / blk, j = lr - tr * blk;     // LDS row -> (triplet of the tile, row of its block)
+        for (int i = 0; i < NAI; ++i) {
+            const int lr = arow4 + 8 * i, tr = lr / blk, j = lr - tr * blk;     // LDS row -> (triplet of the tile, row of its block)
             const int r = min(m0 + kr * tr + (j < kr ? j : 0), M - 1);
             pA[i] = (gfptr)sg.a + (long long)(j < kr ? ((giptr)sg.idx)[r] : ((giptr)sg.idx2)[r]) * sg.lda;
         }
@@ -583,6 +593,7 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
             pB[i] = (gfptr)(i < BH ? sg.b : sg.b2) + (long long)n * sg.ldb;
         }
         f32x4 va4[2][NAI], vb4[2][NBI];
+        float dsum[3] = {0.f, 0.f, 0.f};
         auto vissue = [&](auto set_c, int t) __attribute__((always_inline)) {
             constexpr int SS_ = decltype(set_c)::value;
             const int c = min(t, nst - 1) * BK + 4 * quad;
@@ -595,10 +606,23 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
             constexpr int SS_ = decltype(set_c)::value;
             if (part == 0) {
 #pragma unroll
-                for (int i = 0; i < NAI; ++i) *(f32x4*)(fa + buf * AR * P + (trow + RP * i) * P + 4 * quad) = va4[SS_][i];
+                for (int i = 0; i < NAI; ++i) *(f32x4*)(fa + buf * AR * P + (arow4 + 8 * i) * P + 4 * quad) = va4[SS_][i];
             } else {
 #pragma unroll
                 for (int i = 0; i < NBI; ++i) *(f32x4*)(fb + buf * BR * P + (trow + RP * i) * P + 4 * quad) = vb4[SS_][i];
+            }
+        };
+        // DIST: sum (v_o - v_k + 1e-6)^2 over this thread's column quad (cx.py:300) for row (lane >> 3) + 8 i of the wave's triplet; one item per sub-step
+        // (all three in the sub-step that stores the rows put 26 vector operations behind its last MFMA: 5 790 cycles per k-step against 5 085)
+        auto vdist = [&](auto set_c, int i0, int i1) __attribute__((always_inline)) {
+            constexpr int SS_ = decltype(set_c)::value;
+            if constexpr (DIST) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    if (i < i0 || i >= i1) continue;
+                    const f32x4 df = va4[SS_][3] - va4[SS_][i] + 1e-6f;
+                    dsum[i] += (df[0] * df[0] + df[1] * df[1]) + (df[2] * df[2] + df[3] * df[3]);
+                }
             }
         };
         f32x4 acc4[2][4];
@@ -636,7 +660,7 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
         typedef IntC<0> V0; typedef IntC<1> V1;
         vissue(V0{}, 0);
         vissue(V1{}, 1);
-        vstash(V0{}, 0, 0); vstash(V0{}, 0, 1);
+        vstash(V0{}, 0, 0); vstash(V0{}, 0, 1); vdist(V0{}, 0, 3);
         vissue(V0{}, 2);
         __syncthreads();
         auto vstep = [&](auto par_c, auto last_c, int t) __attribute__((always_inline)) {
@@ -661,16 +685,16 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
                 Frag& nxt = (s & 1) ? x0 : x1;
                 fread(PAR, s + 1, nxt);
                 if (!LAST) {
-                    if (s == 0) vstash(SS{}, PAR ^ 1, 0);
-                    if (s == 1) vstash(SS{}, PAR ^ 1, 1);
-                    if (s == 2) vissue(SS{}, t + 3);
+                    if (s == 0) { vstash(SS{}, PAR ^ 1, 0); vdist(SS{}, 0, 1); }
+                    if (s == 1) { vstash(SS{}, PAR ^ 1, 1); vdist(SS{}, 1, 2); }
+                    if (s == 2) { vdist(SS{}, 2, 3); vissue(SS{}, t + 3); }
                 }
                 fmfma(cur);
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, DIST ? 4 : 3, 0);
                     __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
@@ -683,6 +707,14 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
         if (t + 1 < nst) { vstep(V0{}, Ff{}, t); vstep(V1{}, Tt{}, t + 1); }
         else vstep(V0{}, Tt{}, t);
         fmfma(x1);                                                       // the last sub-step
+        if constexpr (DIST) {                                            // the 8 threads of a row hold its partial sums: reduce, sqrt, park in LDS for the next segment's loader
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                float d2 = dsum[i];
+                d2 += __shfl_xor(d2, 1, 64); d2 += __shfl_xor(d2, 2, 64); d2 += __shfl_xor(d2, 4, 64);
+                if (quad == 0) mf_smem[FOLD_DIST_OFF + 24 * wave + (lane >> 3) + 8 * i] = sqrtf(d2);      // compact tile row (K = 24)
+            }
+        }
         // padded (wave = triplet, 32 rows x 64 columns) -> compact (the 2 x 2 wave layout of the segments that follow), through LDS
         constexpr int CP = 68;
         float* const fc = mf_smem;                                       // [128 padded rows][CP]   (every fragment read is complete: last barrier)
@@ -1120,8 +1152,17 @@ static inline int launch_main_fwd(MainArgs& a, hipStream_t s) {
             }
         }
         if constexpr (CFG::BM % 96 == 0 && CFG::BN == 64 && CFG::WGM * CFG::WGN == CFG::T / 64 && CFG::DEPTH == 2) {      // one triplet per wave (run_vfold4): 96 x 64 / 4 waves, 192 x 64 / 8 waves
-            if (a.split > 1 || a.seg[0].klen % MF_BK || a.seg[0].klen < 2 * MF_BK || !a.epi.rowadd || (a.epi.rowdiv != 24 && a.epi.rowdiv != 48) || a.dist_out)
+            if (a.split > 1 || a.seg[0].klen % MF_BK || a.seg[0].klen < 2 * MF_BK || !a.epi.rowadd || (a.epi.rowdiv != 24 && a.epi.rowdiv != 48))
                 return NCX_E_FLAGS;
+            if (a.dist_out) {                        // the pairwise distance inside the fold: a triplet per wave (K = 24), fp32 forms
+                if constexpr (CFG::X6) return NCX_E_FLAGS;
+                else {
+                    if (a.epi.rowdiv != 24) return NCX_E_FLAGS;
+                    if (is({V, P, P, S})) return launch_main_fwd_seq<CFG, true, V, P, P, S>(a, s);
+                    if (is({V, P, P, P})) return launch_main_fwd_seq<CFG, true, V, P, P, P>(a, s);
+                    return NCX_E_FLAGS;
+                }
+            }
             if (is({V, P, P, S})) return launch_main_fwd_seq<CFG, false, V, P, P, S>(a, s);
             if (is({V, P, P, P})) return launch_main_fwd_seq<CFG, false, V, P, P, P>(a, s);
         }

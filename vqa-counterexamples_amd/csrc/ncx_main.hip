@@ -23,10 +23,7 @@ int main_forward(MainArgs& a, hipStream_t s) {
         // old / young workgroup pair: 0.279-0.282 ms against 0.286-0.293 for two 96 x 64 workgroups per CU at configs[1], bit-identical);
         // 96 x 64 = four triplets per workgroup, two workgroups per CU; 48 x 64 (two triplets) for small batches: twice the workgroups
         // (tools/mb/mb_fold.hip, bit-identical outputs: 293 us against 318).
-        int rows = main_fold_rows(a.M, a.N);
-        if (a.epi.rowdiv == 48 && rows == 48) rows = 96;                       // (K = 48 exists on the one-triplet-per-wave forms only)
-        if (const char* f4 = hook_env("NCX_FOLD4")) rows = atoi(f4) != 0 ? 96 : (a.epi.rowdiv == 48 ? 96 : 48);
-        if (const char* f8 = hook_env("NCX_FOLD8")) rows = atoi(f8) != 0 ? 192 : (rows == 192 ? 96 : rows);
+        const int rows = main_fold_rows_eff(a.M, a.N, a.epi.rowdiv);
         if (rows == 192 && a.x6 && a.epi.rowdiv == 24) return launch_main_fwd<MainCfgFold8X6>(a, s);      // (K = 24: a triplet per wave)
         return rows == 192 ? launch_main_fwd<MainCfgFold8>(a, s) : rows == 96 ? launch_main_fwd<MainCfgFold4>(a, s) : launch_main_fwd<MainCfgFold>(a, s);
     }
@@ -47,6 +44,15 @@ int main_forward(MainArgs& a, hipStream_t s) {
     if (cfg == 1) return launch_main_fwd<MainCfg1>(a, s);
     if (cfg == 2) return launch_main_fwd<MainCfg2>(a, s);
     return launch_main_fwd<MainCfg0>(a, s);
+}
+
+// ... with the experiment hooks and the K = 48 rule applied: the form main_forward takes
+int main_fold_rows_eff(long long M, long long N, int rowdiv) {
+    int rows = main_fold_rows(M, N);
+    if (rowdiv == 48 && rows == 48) rows = 96;                               // (K = 48 exists on the one-triplet-per-wave forms only)
+    if (const char* f4 = hook_env("NCX_FOLD4")) rows = atoi(f4) != 0 ? 96 : (rowdiv == 48 ? 96 : 48);
+    if (const char* f8 = hook_env("NCX_FOLD8")) rows = atoi(f8) != 0 ? 192 : (rows == 192 ? 96 : rows);
+    return rows;
 }
 
 int main_fold_rows(long long M, long long N) {
