@@ -344,12 +344,10 @@ __global__ __launch_bounds__(512, 1) void k_dw_km8(const float* __restrict__ dpr
         for (int i = 0; i < 4; ++i) {
             if (i < i0 || i >= i1) continue;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc_k[i][j][q] += c[i][j][q];
-                    acc_m[i][j][q] = __builtin_fmaf(c[i][j][q], v[j], acc_m[i][j][q]);
-                }
+            for (int j = 0; j < 2; ++j) {                             // (packed: 2 v_pk_add_f32 + 2 v_pk_fma_f32 per block instead of 8 scalar operations)
+                acc_k[i][j] += c[i][j];
+                acc_m[i][j] = __builtin_elementwise_fma(c[i][j], f32x4{v[j], v[j], v[j], v[j]}, acc_m[i][j]);
+            }
         }
     };
     auto pin = [&]() __attribute__((always_inline)) {

@@ -648,14 +648,17 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
             for (int j = 0; j < 4; ++j) { x.wk[j] = *(const f32x2*)(b + j * 16 * P); x.wm[j] = *(const f32x2*)(b + (64 + j * 16) * P); }
         };
         auto fmfma = [&](const Frag& x) __attribute__((always_inline)) {
+            // (the two k of a fragment pair as ONE v_pk_fma_f32: vector instructions are not free under fp32 MFMAs -- each costs the matrix pipe ~10 cycles,
+            // round 4 -- and this loop had 32 of them per k-step; same fma per element, same bits)
+            f32x2 bw[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bw[j] = __builtin_elementwise_fma(x.vo, x.wm[j], x.wk[j]);      // (hipcc splits most of these back into two v_fma_f32; forcing v_pk_fma_f32 through inline asm measured 4 871 against 5 085 cycles per k-step but lost the hazard handling: wrong results)
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float bw = __builtin_fmaf(x.vo[e], x.wm[j][e], x.wk[j][e]);
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.a[i][e], bw, acc4[i][j], 0, 0, 0);
-                }
+                    for (int i = 0; i < 2; ++i) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.a[i][e], bw[j][e], acc4[i][j], 0, 0, 0);
         };
         typedef IntC<0> V0; typedef IntC<1> V1;
         vissue(V0{}, 0);
