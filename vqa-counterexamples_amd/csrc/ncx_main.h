@@ -652,7 +652,7 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
             // round 4 -- and this loop had 32 of them per k-step; same fma per element, same bits)
             f32x2 bw[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bw[j] = __builtin_elementwise_fma(x.vo, x.wm[j], x.wk[j]);      // (hipcc splits most of these back into two v_fma_f32; forcing v_pk_fma_f32 through inline asm measured 4 871 against 5 085 cycles per k-step but lost the hazard handling: wrong results)
+            for (int j = 0; j < 4; ++j) bw[j] = __builtin_elementwise_fma(x.vo, x.wm[j], x.wk[j]);      // (hipcc splits most of these back into two v_fma_f32; as four v_pk_fma_f32 in an asm block: 4 871 cycles per k-step against 5 085 without the wait states an MFMA reading them needs -- wrong results -- and 5 530 with them)
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
