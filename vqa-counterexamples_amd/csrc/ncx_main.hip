@@ -41,6 +41,7 @@ int main_forward(MainArgs& a, hipStream_t s) {
     }
     int cfg = (a.split <= 1 && tiles96 * 10 >= (long long)num_cus() * 9) ? 2 : 0;
     if (const char* e = hook_env("NCX_MAIN_CFG")) cfg = atoi(e);       // experiment hook (NCX_EXPERIMENT=1)
+    if (cfg == 3) return launch_main_fwd<MainCfgW>(a, s);
     if (cfg == 1) return launch_main_fwd<MainCfg1>(a, s);
     if (cfg == 2) return launch_main_fwd<MainCfg2>(a, s);
     return launch_main_fwd<MainCfg0>(a, s);
