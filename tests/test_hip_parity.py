@@ -808,3 +808,29 @@ def test_distance_inside_the_fold_forms_vs_oracle(form, H, monkeypatch):
     assert (s_in - s_prep).abs().max() <= 2e-6 * max(1.0, float(s_prep.abs().max()))
     a, b = g_in["linear_1.weight"], g_prep["linear_1.weight"]
     assert np.abs(a - b).max() <= 1e-5 * np.abs(b).max()
+
+
+def test_x6_logits_are_as_close_to_fp64_as_the_fp32_kernels(monkeypatch):
+    """What "fp32-grade" means, measured: configs[1] at its full size (B = 512, drawn as it comes), all 12 288 logits of the fp32-MFMA forward and of
+    the NCX_F_X6 forward against the oracle's forward evaluated in FLOAT64 on the same fp32 inputs and weights.  The split-bf16 path may not be
+    further from fp64 than the fp32 kernels are (a factor 1.5 of slack for summation-order luck), and both sit far inside the suite's 1e-4."""
+    from helpers import random_case_f32
+    from neuralcx import _lib, ops
+    d = orc.Dims()
+    params = orc.init_params(d, seed=42)
+    batch = random_case_f32(4242, 512, d)
+    with torch.no_grad():
+        p64 = {k: v.double() for k, v in params.items()}
+        ref64 = orc.forward_faithful(p64, d, batch["image_features"].double(), batch["q_emb"].double(), batch["z_orig"].double(),
+                                     batch["z_knns"].double(), batch["a_knns"].double(), batch["answer_aids"])
+    b, p = to_dev_batch(batch), to_dev_params(params)
+    err = {}
+    for name, flag in (("fp32", 0), ("x6", _lib.NCX_F_X6)):
+        monkeypatch.setattr(ops, "EXTRA_FLAGS", flag)
+        dims = ops.make_dims(b, H=d.H, L=d.L, da=d.da, A=d.A)
+        ws = ops.alloc_workspace(dims, dev())
+        s = ops.forward(dims, b, p, ws).cpu().double()
+        err[name] = float((s - ref64.reshape(s.shape)).abs().max())
+    print("max |logit - fp64|: fp32 kernels %.3e, X6 kernels %.3e" % (err["fp32"], err["x6"]))
+    assert err["fp32"] <= 1e-4 and err["x6"] <= 1e-4
+    assert err["x6"] <= 1.5 * err["fp32"] + 1e-7
