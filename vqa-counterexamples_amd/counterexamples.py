@@ -77,6 +77,7 @@ def build_parser():
     p.add_argument("--max_steps", type=int, default=-1, help="stop an epoch early (smoke runs)")
     p.add_argument("--no_vqa_cache", action="store_true", help="produce q / z / answer logits per batch instead of once per split")
     p.add_argument("--bf16", action="store_true", help="bf16 operands on the two dominant GEMMs (fp32 accumulate / master weights)")
+    p.add_argument("--x6", action="store_true", help="NCX_F_X6: the three big fp32 products on the bf16 matrix cores with three-plane fp32-grade operands (same results to fp32 rounding; not the default)")
     p.add_argument("--path_trainset", type=str, default=None, help="overrides vqa.path_trainset of the YAML")
     p.add_argument("--path_features", type=str, default=None, help="overrides coco.path_features / path_raw of the YAML")
     return p
@@ -111,7 +112,7 @@ class Runner:
                                      A=options["vqa"]["nans"], H=cx["dim_h"], L=cx["n_layers"], drop_p=cx["drop_p"],
                                      lr=options["optim"]["lr"], device=self.dev,
                                      spec={k: cx.get(k, True) for k in ("v_mult", "v_dist", "v_rank", "a_emb")},
-                                     world_size=self.world, bf16=args.bf16)
+                                     world_size=self.world, bf16=args.bf16, x6=getattr(args, "x6", False))
         self.engine.rank = self.rank
         self.engine.init_parameters(seed=42)
         self.gb = options["optim"]["batch_size"]
