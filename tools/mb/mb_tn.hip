@@ -776,6 +776,195 @@ __global__ __launch_bounds__(512, 1) void k_tn8x6p(const TnArgs a) {
         }
 }
 
+
+// 256 x 128 tiles on the bf16 x 6 path: a wave owns 64 x 64 (fragment bytes per flop -33 %, operand loads per flop -40 % against 256 x 64); the column
+// fragments of a step are read once (no carry over the barrier: 48 registers), LDS = 2 x 3 x 32 x (544 + 288) = 159 744 bytes.
+template <bool SOFTMAX>
+__global__ __launch_bounds__(512, 1) void k_tn8x6w(const TnArgs a) {
+    constexpr int T = 512, BM = 256, BN = 128, BK = 32;
+    constexpr int PA = 544, PB = 288;
+    constexpr int A_PL = BK * PA, B_PL = BK * PB, PL = A_PL + B_PL;
+    constexpr int BUF = 3 * PL;
+    constexpr int NA = 4, NX = 2;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char sm6[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int wm0 = 64 * (wave >> 1), wn0 = 64 * (wave & 1);
+    int id = blockIdx.x, tile, z, nz;
+    if (id < a.n_hi * (a.S + 1)) { tile = id / (a.S + 1); z = id - tile * (a.S + 1); nz = a.S + 1; }
+    else { id -= a.n_hi * (a.S + 1); tile = a.n_hi + id / a.S; z = id - (tile - a.n_hi) * a.S; nz = a.S; }
+    const int n0 = tile * BN;
+    const int total_steps = a.M / BK;
+    const int g0 = (int)((long long)total_steps * z / nz), g1 = (int)((long long)total_steps * (z + 1) / nz);
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int arow = tid >> 6, aq = tid & 63;                 // A: rows arow + 8 i, quad aq
+    const int brow = tid >> 5, bq = tid & 31;                 // X: rows brow + 16 i, quad bq (32 quads per 128-column row)
+    const int bcc = min(n0 + 4 * bq, a.N - 4);
+    f32x4 va[2][NA], vb[2][NX];
+    float vl[2][NX];
+    auto issue = [&](auto set_c, int t) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_c)::value;
+        const int r0 = min(t, g1 - 1) * BK;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) va[S][i] = *(gf4ptr)((gfptr)a.D + (long long)(r0 + arow + 8 * i) * a.H + 4 * aq);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            vb[S][i] = *(gf4ptr)((gfptr)a.X + (long long)(r0 + brow + 16 * i) * a.ldx + bcc);
+            if (SOFTMAX) vl[S][i] = ((gfptr)a.lse)[r0 + brow + 16 * i];
+        }
+    };
+    auto split_store = [&](f32x4 v, unsigned char* base) __attribute__((always_inline)) {
+        unsigned p1[4], p2[4], p3[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xj = v[j];
+            p1[j] = __builtin_bit_cast(unsigned, xj) & 0xFFFF0000u;
+            const float r1 = xj - __builtin_bit_cast(float, p1[j]);
+            p2[j] = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+            const float r2 = r1 - __builtin_bit_cast(float, p2[j]);
+            p3[j] = __builtin_bit_cast(unsigned, r2);
+        }
+        const u32x2 w1 = {__builtin_amdgcn_perm(p1[1], p1[0], 0x07060302u), __builtin_amdgcn_perm(p1[3], p1[2], 0x07060302u)};
+        const u32x2 w2 = {__builtin_amdgcn_perm(p2[1], p2[0], 0x07060302u), __builtin_amdgcn_perm(p2[3], p2[2], 0x07060302u)};
+        const u32x2 w3 = {__builtin_amdgcn_perm(p3[1], p3[0], 0x07060302u), __builtin_amdgcn_perm(p3[3], p3[2], 0x07060302u)};
+        *(u32x2*)(base) = w1; *(u32x2*)(base + PL) = w2; *(u32x2*)(base + 2 * PL) = w3;
+    };
+    auto stash = [&](auto set_c, int buf, int h0, int h1) __attribute__((always_inline)) {        // items 0 .. 3: A quads, 4 .. 5: X quads
+        constexpr int S = decltype(set_c)::value;
+        unsigned char* const base = sm6 + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (i < h0 || i >= h1) continue;
+            split_store(va[S][i], base + (arow + 8 * i) * PA + aq * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            if (NA + i < h0 || NA + i >= h1) continue;
+            f32x4 v = vb[S][i];
+            if (SOFTMAX) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float xj = v[j]; v[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(xj, 1.44269504088896341f, -vl[S][i])); }
+            }
+            split_store(v, base + A_PL + (brow + 16 * i) * PB + bq * 8);
+        }
+    };
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+    const int tq = li >> 2, tp = li & 3;
+    const int offA = (4 * lk + tq) * PA + (wm0 + 4 * tp) * 2, offB = A_PL + (4 * lk + tq) * PB + (wn0 + 4 * tp) * 2;
+    auto read_a = [&](int buf, int i, bf16x8 (&af)[3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const unsigned char* ta = sm6 + buf * BUF + p * PL + offA + i * 32;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ta));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ta + 16 * PA));
+            af[p] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+    };
+    auto read_b = [&](int buf, bf16x8 (&bf)[3][4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned char* tb = sm6 + buf * BUF + p * PL + offB + j * 32;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tb));
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tb + 16 * PB));
+                bf[p][j] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+    };
+    auto mfma24 = [&](const bf16x8 (&af)[3], const bf16x8 (&bf)[3][4], f32x4 (&c)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[2][j], c[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[1][j], c[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bf[0][j], c[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[1][j], c[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bf[0][j], c[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bf[0][j], c[j], 0, 0, 0);
+    };
+    auto pin = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 24; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    typedef IntC<0> S0; typedef IntC<1> S1;
+    issue(S0{}, g0);
+    issue(S1{}, g0 + 1);
+    stash(S0{}, 0, 0, NA + NX);
+    issue(S0{}, g0 + 2);
+    __syncthreads();
+    auto step = [&](auto par_c, int t) __attribute__((always_inline)) {
+        constexpr int PAR = decltype(par_c)::value;
+        typedef IntC<PAR ^ 1> SS;
+        bf16x8 bfr[3][4], afA[3], afB[3];
+        read_b(PAR, bfr);
+        read_a(PAR, 0, afA);
+        read_a(PAR, 1, afB); stash(SS{}, PAR ^ 1, 0, 2); mfma24(afA, bfr, acc[0]); pin();
+        read_a(PAR, 2, afA); stash(SS{}, PAR ^ 1, 2, 4); mfma24(afB, bfr, acc[1]); pin();
+        read_a(PAR, 3, afB); stash(SS{}, PAR ^ 1, 4, 6); mfma24(afA, bfr, acc[2]); pin();
+        issue(SS{}, t + 3); mfma24(afB, bfr, acc[3]); pin();
+        __syncthreads();
+    };
+    int t = g0;
+    for (; t + 1 < g1; t += 2) { step(IntC<0>{}, t); step(IntC<1>{}, t + 1); }
+    if (t < g1) step(IntC<0>{}, t);
+    float* const slot = a.slab + (long long)blockIdx.x * (BM * BN);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int row = wm0 + 16 * i + 4 * lk + rg;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) slot[row * BN + wn0 + 16 * j + li] = acc[i][j][rg];
+        }
+}
+
+template <bool SOFTMAX>
+static float run_x6w(const TnArgs& a0, int wgs_target, int reps, float* out, bool verbose, const char* name) {
+    constexpr int BN = 128;
+    TnArgs a = a0;
+    a.tiles_n = (a.N + BN - 1) / BN;
+    a.S = wgs_target / a.tiles_n; if (a.S < 1) a.S = 1;
+    a.n_hi = wgs_target - a.S * a.tiles_n; if (a.n_hi < 0 || a.n_hi > a.tiles_n) a.n_hi = 0;
+    const int wgs = a.S * a.tiles_n + a.n_hi;
+    const int lds = 2 * 3 * 32 * (544 + 288);
+    CHECK(hipFuncSetAttribute((const void*)k_tn8x6w<SOFTMAX>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    CHECK(hipMalloc(&a.slab, (size_t)wgs * 256 * BN * 4));
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k_tn8x6w<SOFTMAX>), dim3(wgs), dim3(512), lds, 0, a);
+    CHECK(hipDeviceSynchronize());
+    std::vector<float> ts;
+    for (int i = 0; i < reps; ++i) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL((k_tn8x6w<SOFTMAX>), dim3(wgs), dim3(512), lds, 0, a);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms);
+    }
+    std::sort(ts.begin(), ts.end());
+    const float med = ts[ts.size() / 2];
+    if (out) {
+        hipLaunchKernelGGL((k_reduce<BN>), dim3((unsigned)(((long long)256 * a.N + 255) / 256)), dim3(256), 0, 0, a.slab, 256, a.N, a.S, a.n_hi, out);
+        CHECK(hipDeviceSynchronize());
+    }
+    const double gf = 2.0 * a.M * 256.0 * a.N / 1e9;
+    if (verbose) printf("%-34s wgs %3d (S %d)  lds %6d  min %.1f med %.1f us  %.1f TFLOP/s fp32-equivalent (%.3f of the 157.3 fp32-MFMA peak)  slab %.1f MB\n", name, wgs, a.S, lds,
+                        ts[0] * 1e3, med * 1e3, gf / med, gf / med / 157.3, wgs * 256.0 * BN * 4 / 1e6);
+    CHECK(hipFree(a.slab));
+    return med;
+}
+
 template <bool SOFTMAX, int VARIANT>
 static float run_x6p(const TnArgs& a0, int wgs_target, int reps, float* out, bool verbose, const char* name) {
     constexpr int BN = 64;
@@ -995,6 +1184,7 @@ int main(int argc, char** argv) {
     run_x6p<true, 1>(a, 256, reps, dout, true, "256x64  bf16 x 6 pipelined, load burst"); check("256x64 bf16x6 pipelined v1");
     run_x6p<false, 0>(a, 256, reps, nullptr, true, "256x64  bf16 x 6 pipelined plain");
     run_x6p<true, 20>(a, 256, reps, dout, true, "256x64  bf16 x 6, 3 load sets"); check("256x64 bf16x6 3 sets");
+    run_x6w<true>(a, 256, reps, dout, true, "256x128 bf16 x 6"); check("256x128 bf16x6");
     run_x6p<true, 15>(a, 256, reps, nullptr, true, "   x6p ABL loads of the same 4 tiles");
     run_x6p<true, 16>(a, 256, reps, nullptr, true, "   x6p ABL stores do not depend on loads");
     run_x6p<true, 10>(a, 256, reps, nullptr, true, "   x6p ABL no split arithmetic");
