@@ -292,17 +292,24 @@ __global__ __launch_bounds__(512, 1) void k_dw_km8(const float* __restrict__ dpr
         return brow < K ? ((gip)idx_k)[r0 + brow] : ((gip)idx_o)[r0];
     };
     int ixn = load_idx(b0);                                        // gather row of the NEXT issue (requested one issue ahead)
+    // Addresses as UNIFORM base (scalar registers, scalar arithmetic) + a 32-bit per-lane byte offset that never changes (dpre rows) or costs one
+    // v_mad_u32_u24 (the gathered feature row: n_img x dv x 4 < 2^32): vector instructions are not hidden under fp32 MFMAs (DESIGN S5d), and the 64-bit
+    // multiply-adds of `base + (r0 + row) * H` per load were a fifth of this loop's.
+    unsigned offA[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) offA[i] = (unsigned)(((arow + 8 * i) * H + m0 + 4 * aq) * 4);
+    const unsigned offX = (unsigned)((n0 + 4 * bq) * 4), dv4 = (unsigned)dv * 4u;
     auto issue = [&](auto set_c, int b) __attribute__((always_inline)) {
         constexpr int SS_ = decltype(set_c)::value;
         const long long r0 = (long long)min(b, b1 - 1) * K;
-        const gfp ap = (gfp)dpre + (r0 + arow) * H + m0 + 4 * aq;
+        const char* const abase = (const char*)(dpre + r0 * H);          // uniform
         // (the index request goes out FIRST: it is the load the next issue needs soonest, and vmcnt counts in order -- as the youngest load of the
         // issue it made the next issue wait for every quad of this one)
         const int ix = ixn;
         ixn = load_idx(b + 1);
 #pragma unroll
-        for (int i = 0; i < NA; ++i) va[SS_][i] = *(gf4p)(ap + (long long)(8 * i) * H);
-        vb[SS_] = *(gf4p)((gfp)feats + (long long)ix * dv + n0 + 4 * bq);
+        for (int i = 0; i < NA; ++i) va[SS_][i] = *(gf4p)(abase + offA[i]);
+        vb[SS_] = *(gf4p)((const char*)feats + (__umul24((unsigned)ix, dv4) + offX));
     };
     auto stash = [&](auto set_c, int buf, int h0, int h1) __attribute__((always_inline)) {
         constexpr int SS_ = decltype(set_c)::value;
