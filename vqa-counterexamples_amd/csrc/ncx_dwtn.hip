@@ -138,32 +138,73 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
     const int brow = tid >> 4, bq = tid & 15;                   // X item: tile row brow, quad bq
     f32x4 va[2][NA], vb[2];
     float vl[2], vs[2];                                         // lse of the X item's row; 1 = softmax piece
-    int qi = 0;                                                 // piece of the NEXT issue
-    Tn8Seg dn = segs[0];
-    // ... and so does the gathered row of the X item (an index read inside issue() would put an LDS round trip in front of its load)
-    auto gather_row = [&](const Tn8Seg& sg, int v) __attribute__((always_inline)) -> int {
-        const int r = (sg.t0 + (min(v, V - 1) - sg.vbeg)) * BK + brow;
-        return lds_idx[(sg.gsel == 2 ? a.B : 0) + (sg.gsel ? min(r, a.B - 1) : 0)];
-    };
-    int rgn = gather_row(dn, 0);
-    auto issue = [&](auto set_c, int v) __attribute__((always_inline)) {
-        constexpr int S = decltype(set_c)::value;
-        // (virtual steps beyond the sequence re-load the last tile; never consumed)
-        const int vv = min(v, V - 1);
-        const int t = dn.t0 + (vv - dn.vbeg);
-        const long long r0 = (long long)t * BK;
-        const tn_gfptr ap = (tn_gfptr)(uintptr_t)dn.a_ptr + (r0 + arow) * a.H + 4 * aq;
+    // Vector instructions are not hidden under fp32 MFMAs (DESIGN S5d: each costs the matrix pipe ~10 cycles), and the loader that recomputed every address from
+    // the piece record cost ~25 of them per k-step.  So an issue is `uniform base + 32-bit lane offset`, the bases advanced by scalar arithmetic (issue_fast, the
+    // only loader code inside a step); whenever the NEXT issue enters a new piece, needs the row clamp (the last rows of a padded problem) or runs past the
+    // sequence, loader_switch() re-derives the state from the piece record BETWEEN two steps (a uniform branch in the loop, not in the step).  Same addresses,
+    // same values as before: results are bit-identical.
+    int lq = 0, l_vend = 0;                                     // uniform: piece of the last switch; first virtual step the advanced state is NOT valid for
+    const char *aB = nullptr, *xB = nullptr, *lB = nullptr;     // uniform bases of the next issue
+    unsigned aS = 0, xS = 0, lS = 0, ldx4 = 0;                  // uniform strides per k-step (bytes); row pitch of the gathered operand (bytes)
+    int gselP = 0, tN = 0;
+    float vsP = 0.f;
+    unsigned offA[NA], offX = 0, offL = 0;                      // per-lane byte offsets
 #pragma unroll
-        for (int i = 0; i < NA; ++i) va[S][i] = *(tn_gf4ptr)(ap + (long long)(8 * i) * a.H);
-        const int r = (int)r0 + brow;
-        const long long xr = dn.gsel ? (long long)rgn : (long long)min(r, dn.rv - 1);
-        vb[S] = *(tn_gf4ptr)((tn_gfptr)(uintptr_t)dn.x_ptr + xr * dn.ldx + min(dn.n0 + 4 * bq, dn.ncl));
-        vl[S] = ((tn_gfptr)(uintptr_t)dn.l_ptr)[dn.soft ? min(r, dn.rv - 1) : 0];
-        vs[S] = dn.soft ? 1.f : 0.f;
-        // the record of the next issue (read now, used one k-step from now)
-        qi += (v + 1 >= dn.vend && qi + 1 < nseg) ? 1 : 0;
-        dn = segs[qi];
-        rgn = gather_row(dn, v + 1);
+    for (int i = 0; i < NA; ++i) offA[i] = (unsigned)(((arow + 8 * i) * a.H + 4 * aq) * 4);
+    int rgn = 0;                                                // gathered row of the next issue
+    auto rfl = [&](int x) __attribute__((always_inline)) -> int { return __builtin_amdgcn_readfirstlane(x); };
+    auto rfl64 = [&](unsigned long long x) __attribute__((always_inline)) -> unsigned long long {
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x);
+    };
+    auto gather_at = [&](int t) __attribute__((always_inline)) -> int {       // (always executed: a clamped LDS read; used only by gathered pieces)
+        return lds_idx[(gselP == 2 ? a.B : 0) + min(t * BK + brow, a.B - 1)];
+    };
+    auto loader_switch = [&](int v) {                // make the state valid for the issue of virtual step v
+        const int vv = min(v, V - 1);                            // (virtual steps beyond the sequence re-load the last tile; never consumed)
+        int q = lq;
+        while (q + 1 < nseg && vv >= segs[q].vend) ++q;
+        q = rfl(q);
+        const Tn8Seg sg = segs[q];
+        const unsigned long long a_ptr = rfl64(sg.a_ptr), x_ptr = rfl64(sg.x_ptr), l_ptr = rfl64(sg.l_ptr);
+        const int ldx = rfl(sg.ldx), soft = rfl(sg.soft), gsel = rfl(sg.gsel), n0 = rfl(sg.n0), ncl = rfl(sg.ncl), t0 = rfl(sg.t0), vbeg = rfl(sg.vbeg),
+                  vend = rfl(sg.vend), rv = rfl(sg.rv);
+        const int t = t0 + (vv - vbeg);
+        const long long r0 = (long long)t * BK;
+        const bool clamp = !gsel && r0 + BK > rv;                // some row of THIS step lies beyond the rows that exist: per-lane row clamp, one step
+        const int col = min(n0 + 4 * bq, ncl), r = (int)r0 + brow;
+        lq = q; tN = t; gselP = gsel; vsP = soft ? 1.f : 0.f; ldx4 = (unsigned)ldx * 4u;
+        aB = (const char*)(uintptr_t)a_ptr + r0 * a.H * 4;
+        if (gsel)       { xB = (const char*)(uintptr_t)x_ptr;                 offX = (unsigned)(col * 4); }
+        else if (clamp) { xB = (const char*)(uintptr_t)x_ptr;                 offX = (unsigned)(((long long)min(r, rv - 1) * ldx + col) * 4); }
+        else            { xB = (const char*)(uintptr_t)x_ptr + r0 * ldx * 4;  offX = (unsigned)((brow * ldx + col) * 4); }
+        if (!soft)      { lB = (const char*)(uintptr_t)l_ptr;                 offL = 0u; }
+        else if (clamp) { lB = (const char*)(uintptr_t)l_ptr;                 offL = (unsigned)(min(r, rv - 1) * 4); }
+        else            { lB = (const char*)(uintptr_t)l_ptr + r0 * 4;        offL = (unsigned)(brow * 4); }
+        if (v >= V - 1) {                                        // the last tile of the sequence, and every issue after it: stay
+            aS = 0; xS = 0; lS = 0; l_vend = 0x7fffffff;
+        } else {
+            aS = (unsigned)(BK * a.H * 4); xS = (gsel || clamp) ? 0u : (unsigned)(BK * ldx * 4); lS = (soft && !clamp) ? (unsigned)(BK * 4) : 0u;
+            // valid until the piece ends, the first step that needs the clamp, or the last step of the sequence (which switches to "stay")
+            int ve = min(vend, V - 1);
+            if (!gsel && (long long)(t0 + (vend - vbeg)) * BK > (long long)rv) ve = min(ve, vbeg + (rv / BK - t0));      // (step rv / BK is the first with a row beyond rv)
+            l_vend = clamp ? v + 1 : max(ve, v + 1);
+        }
+        rgn = gather_at(t);
+    };
+    auto issue_fast = [&](auto set_c) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_c)::value;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) va[S][i] = *(tn_gf4ptr)(aB + offA[i]);
+        const unsigned xo = gselP ? __umul24((unsigned)rgn, ldx4) + offX : offX;
+        vb[S] = *(tn_gf4ptr)(xB + xo);
+        vl[S] = *(tn_gfptr)(lB + offL);
+        vs[S] = vsP;
+        aB += aS; xB += xS; lB += lS; ++tN;
+        rgn = gather_at(tN);
+    };
+    auto issue = [&](auto set_c, int v) __attribute__((always_inline)) {        // (prologue)
+        if (v >= l_vend) loader_switch(v);
+        issue_fast(set_c);
     };
     auto stash = [&](auto set_c, int buf, int h0, int h1) __attribute__((always_inline)) {
         constexpr int S = decltype(set_c)::value;
@@ -238,7 +279,7 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
             read_frags(PAR, s + 1, afn, bfn);
             if (s == 0) stash(SS{}, PAR ^ 1, 0, 2);
             if (s == 1) stash(SS{}, PAR ^ 1, 2, NA + 1);
-            if (s == 2) issue(SS{}, v + 3);
+            if (s == 2) issue_fast(SS{});                     // (virtual step v + 3: the loop made the state valid for it)
             mfma(afc, bfc);
 #pragma unroll
             for (int q = 0; q < NMF; ++q) {
@@ -261,8 +302,13 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
         }
     };
     int v = 0;
-    for (; v + 1 < V; v += 2) { step(S0{}, v); step(S1{}, v + 1); }
-    if (v < V) step(S0{}, v);
+    for (; v + 1 < V; v += 2) {
+        if (v + 3 >= l_vend) loader_switch(v + 3);
+        step(S0{}, v);
+        if (v + 4 >= l_vend) loader_switch(v + 4);
+        step(S1{}, v + 1);
+    }
+    if (v < V) { if (v + 3 >= l_vend) loader_switch(v + 3); step(S0{}, v); }
 }
 
 
