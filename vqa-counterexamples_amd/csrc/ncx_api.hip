@@ -1231,7 +1231,8 @@ static int forward_impl(const ncx_dims* dp, const ncx_inputs* in, const ncx_para
     // K = 24, whole 32-column tiles, no k-split: the two v segments as one pass with the per-triplet fold (ncx_main.h, MK_VFOLD)
     // (K = 48: on 96-row tiles only -- two triplets per tile -- so only where those fill the chip)
     const bool vfold = main_fwd_dims_ok(d) && (d.flags & NCX_F_V_MULT) && (d.K == 24 || (d.K == 48 && (main_fold_rows(M, H) >= 96 || hook_env("NCX_FOLD4") || hook_env("NCX_FOLD8")))) && d.dv % 32 == 0 && d.dv >= 64 &&
-                       main_split(M, H, main_T) == 1 && !hook_env("NCX_NO_VFOLD");
+                       main_split(M, H, main_T) == 1 && !hook_env("NCX_NO_VFOLD") &&
+                       (long long)d.n_img * d.dv * 4 < (1ll << 32) - 65536 && (long long)H * din * 4 < (1ll << 32) - 65536;      // (the fold's buffer loads: 32-bit byte offsets)
     // Measured at configs[1]: inside the plain chain the distance costs the kernel 12 us and saves k_prep 30; inside the fold's
     // 48 x 64 tiles (a quarter of the MFMA work per vector instruction) it costs 31 us: there k_prep keeps computing it.
     // Round 4, measured again for the one-triplet-per-wave fold forms (96 / 192-row tiles, K = 24: a wave's loader holds v_o beside every v_k quad it loads,

@@ -577,7 +577,13 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
         // kr = 24: four triplets, 32-row blocks (24 v_k rows, v_o, 7 spare); kr = 48 (K = 48): two triplets, 64-row blocks (48 v_k rows,
         // v_o, 15 spare) -- 4 MFMA row blocks per 48 rows against the 6 of the two plain segments, like 4 per 24 against 2 x 3
         const int kr = args.epi.rowdiv, blk = kr == 24 ? 32 : 64;
-        gfptr pA[NAI], pB[NBI];
+        // Operand loads as buffer loads: descriptor (uniform base) + a 32-bit per-lane byte offset that never changes (row x pitch + quad) + a uniform
+        // 32-bit step offset in a scalar register -- NO vector instruction per load (the 64-bit `pointer + column` add per load was 6 of this loop's ~38
+        // vector instructions per k-step, and those are not hidden under fp32 MFMAs: DESIGN S5d).  Host-checked: every operand extent < 4 GiB.
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.a), 0, 0xFFFFFFF0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.b), 0, 0xFFFFFFF0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.b2), 0, 0xFFFFFFF0u, 0x00020000);
+        unsigned voA[NAI], voB[NBI];
         // loader item i of this thread: A row 32 wave + (lane >> 3) + 8 i -- a wave loads the rows of ITS 32-row block, so at K = 24 item 3 (block rows 24 ..
         // 31: v_o, every one of them) gives every lane the v_o quad of the columns its v_k items cover: the pairwise distance needs no exchange
         const int arow4 = 32 * wave + (lane >> 3);
@@ -585,22 +591,23 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
         for (int i = 0; i < NAI; ++i) {
             const int lr = arow4 + 8 * i, tr = lr / blk, j = lr - tr * blk;     // LDS row -> (triplet of the tile, row of its block)
             const int r = min(m0 + kr * tr + (j < kr ? j : 0), M - 1);
-            pA[i] = (gfptr)sg.a + (long long)(j < kr ? ((giptr)sg.idx)[r] : ((giptr)sg.idx2)[r]) * sg.lda;
+            voA[i] = (unsigned)(j < kr ? ((giptr)sg.idx)[r] : ((giptr)sg.idx2)[r]) * (unsigned)(sg.lda * 4) + 16u * quad;
         }
 #pragma unroll
         for (int i = 0; i < NBI; ++i) {                     // ... and W row trow + RP i of [W_k (64 rows) ; W_m (64 rows)]
             const int n = min(n0 + trow + RP * (i % BH), N - 1);
-            pB[i] = (gfptr)(i < BH ? sg.b : sg.b2) + (long long)n * sg.ldb;
+            voB[i] = (unsigned)n * (unsigned)(sg.ldb * 4) + 16u * quad;
         }
         f32x4 va4[2][NAI], vb4[2][NBI];
         float dsum[3] = {0.f, 0.f, 0.f};
+        typedef unsigned int bu32x4 __attribute__((ext_vector_type(4)));
         auto vissue = [&](auto set_c, int t) __attribute__((always_inline)) {
             constexpr int SS_ = decltype(set_c)::value;
-            const int c = min(t, nst - 1) * BK + 4 * quad;
+            const int so = min(t, nst - 1) * (BK * 4);            // uniform byte offset of the k-step
 #pragma unroll
-            for (int i = 0; i < NAI; ++i) va4[SS_][i] = *(gf4ptr)(pA[i] + c);
+            for (int i = 0; i < NAI; ++i) va4[SS_][i] = __builtin_bit_cast(f32x4, (bu32x4)__builtin_amdgcn_raw_buffer_load_b128(rsA, voA[i], so, 0));
 #pragma unroll
-            for (int i = 0; i < NBI; ++i) vb4[SS_][i] = *(gf4ptr)(pB[i] + c);
+            for (int i = 0; i < NBI; ++i) vb4[SS_][i] = __builtin_bit_cast(f32x4, (bu32x4)__builtin_amdgcn_raw_buffer_load_b128(i < BH ? rsK : rsM, voB[i], so, 0));
         };
         auto vstash = [&](auto set_c, int buf, int part) __attribute__((always_inline)) {      // part 0: the A rows, part 1: W_k | W_m
             constexpr int SS_ = decltype(set_c)::value;
