@@ -295,6 +295,9 @@ __global__ __launch_bounds__(512, 1) void k_dw_km8(const float* __restrict__ dpr
     // Addresses as UNIFORM base (scalar registers, scalar arithmetic) + a 32-bit per-lane byte offset that never changes (dpre rows) or costs one
     // v_mad_u32_u24 (the gathered feature row: n_img x dv x 4 < 2^32): vector instructions are not hidden under fp32 MFMAs (DESIGN S5d), and the 64-bit
     // multiply-adds of `base + (r0 + row) * H` per load were a fifth of this loop's.
+    typedef unsigned int bu32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dpre), 0, 0xFFFFFFF0u, 0x00020000);      // (buffer loads: no vector instruction per load)
+    const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(feats), 0, 0xFFFFFFF0u, 0x00020000);
     unsigned offA[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) offA[i] = (unsigned)(((arow + 8 * i) * H + m0 + 4 * aq) * 4);
@@ -302,14 +305,14 @@ __global__ __launch_bounds__(512, 1) void k_dw_km8(const float* __restrict__ dpr
     auto issue = [&](auto set_c, int b) __attribute__((always_inline)) {
         constexpr int SS_ = decltype(set_c)::value;
         const long long r0 = (long long)min(b, b1 - 1) * K;
-        const char* const abase = (const char*)(dpre + r0 * H);          // uniform
+        const unsigned ao = (unsigned)(r0 * H * 4);                      // uniform
         // (the index request goes out FIRST: it is the load the next issue needs soonest, and vmcnt counts in order -- as the youngest load of the
         // issue it made the next issue wait for every quad of this one)
         const int ix = ixn;
         ixn = load_idx(b + 1);
 #pragma unroll
-        for (int i = 0; i < NA; ++i) va[SS_][i] = *(gf4p)(abase + offA[i]);
-        vb[SS_] = *(gf4p)((const char*)feats + (__umul24((unsigned)ix, dv4) + offX));
+        for (int i = 0; i < NA; ++i) va[SS_][i] = __builtin_bit_cast(f32x4, (bu32x4)__builtin_amdgcn_raw_buffer_load_b128(rsD, offA[i], ao, 0));
+        vb[SS_] = __builtin_bit_cast(f32x4, (bu32x4)__builtin_amdgcn_raw_buffer_load_b128(rsF, __umul24((unsigned)ix, dv4) + offX, 0, 0));
     };
     auto stash = [&](auto set_c, int buf, int h0, int h1) __attribute__((always_inline)) {
         constexpr int SS_ = decltype(set_c)::value;
@@ -701,7 +704,8 @@ int dw_km(const ncx_dims& d, const float* dpre, const float* feats, const int* i
     constexpr int R = 24;
     // the 8-wave 256 x 64 form where the shape has whole tiles (configs[1] on one box: DW1C 0.2962-0.2970 ms against 0.3048, step 0.8465-0.8478 ms against 0.8578)
     const bool x6 = (d.flags & NCX_F_X6) && !hook_env("NCX_NO_X6") && !hook_env("NCX_NO_KM_X6");
-    if (d.H % 256 == 0 && d.dv % 64 == 0 && !x6 && !hook_env("NCX_NO_KM8") && !hook_env("NCX_KM_BM") && !hook_env("NCX_KM_T") && !hook_env("NCX_KM_ABL")) {
+    const bool fits32 = (long long)d.n_img * d.dv * 4 < (1ll << 32) - 65536 && (long long)d.B * d.K * d.H * 4 < (1ll << 32) - 65536;      // (k_dw_km8's buffer loads: 32-bit byte offsets)
+    if (d.H % 256 == 0 && d.dv % 64 == 0 && fits32 && !x6 && !hook_env("NCX_NO_KM8") && !hook_env("NCX_KM_BM") && !hook_env("NCX_KM_T") && !hook_env("NCX_KM_ABL")) {
         static DevMask attr8{0};
         NCX_HIP_TRY(set_max_lds_once(attr8, (const void*)k_dw_km8, KM8_LDS));
         hipLaunchKernelGGL(k_dw_km8, dim3((d.H / 256) * (d.dv / 64) * S), dim3(512), KM8_LDS, s, dpre, d.H, feats, d.dv, idx_k, idx_o, d.B, d.K, chunk, d.H / 256, S, slab);

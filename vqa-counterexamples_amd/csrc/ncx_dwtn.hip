@@ -113,7 +113,8 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
     float* const lds_a = tn_smem;                               // [2][32][PA]
     float* const lds_b = tn_smem + 2 * BK * PA;                 // [2][32][PB]
     Tn8Seg* const segs = (Tn8Seg*)(tn_smem + 2 * BK * (PA + PB));          // [TN8_MAX_SEG]
-    int* const lds_idx = (int*)(segs + TN8_MAX_SEG);            // [2][B]: idx_ob, answer ids (row gathers of the per-triplet problems)
+    int* const lds_idx = (int*)(segs + TN8_MAX_SEG);            // [2][B + 32]: idx_ob, answer ids (row gathers of the per-triplet problems; 32 spare entries: the loader reads one step ahead)
+    const int IB = a.B + 32;
     __shared__ int s_nseg, s_vtot;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int wm0 = 64 * (wave >> 1), wn0 = 32 * (wave & 1);
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
 
     if (tid == 0) tn8_pieces(a, w, segs, &s_nseg, &s_vtot);
     if (a.do_rest) {                                            // row-gather tables of the per-triplet problems
-        for (int i = tid; i < a.B; i += T) { lds_idx[i] = a.idx_ob ? a.idx_ob[i] : 0; lds_idx[a.B + i] = a.aid ? a.aid[i] : 0; }
+        for (int i = tid; i < IB; i += T) { const int ii = min(i, a.B - 1); lds_idx[i] = a.idx_ob ? a.idx_ob[ii] : 0; lds_idx[IB + i] = a.aid ? a.aid[ii] : 0; }
     }
     __syncthreads();
     const int nseg = s_nseg, V = s_vtot;
@@ -144,9 +145,13 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
     // sequence, loader_switch() re-derives the state from the piece record BETWEEN two steps (a uniform branch in the loop, not in the step).  Same addresses,
     // same values as before: results are bit-identical.
     int lq = 0, l_vend = 0;                                     // uniform: piece of the last switch; first virtual step the advanced state is NOT valid for
-    const char *aB = nullptr, *xB = nullptr, *lB = nullptr;     // uniform bases of the next issue
+    // (buffer loads: descriptor = the piece's operand base, voffset = the lane's constant offset, soffset = the step's uniform offset: no vector instruction per load)
+    // (the one-float lse load keeps its pointer: a third descriptor did not stay in scalar registers and hipcc wrapped that load in a waterfall loop)
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)nullptr, 0, 0, 0x00020000), rsX = rsA;
+    const char* lB = nullptr;
+    unsigned aO = 0, xO = 0;                                    // uniform byte offsets of the next issue
     unsigned aS = 0, xS = 0, lS = 0, ldx4 = 0;                  // uniform strides per k-step (bytes); row pitch of the gathered operand (bytes)
-    int gselP = 0, tN = 0;
+    int gi = 0, gS = 0;                                         // per-lane index into the gather tables for the issue after next; its uniform stride (0: no gather)
     float vsP = 0.f;
     unsigned offA[NA], offX = 0, offL = 0;                      // per-lane byte offsets
 #pragma unroll
@@ -155,9 +160,6 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
     auto rfl = [&](int x) __attribute__((always_inline)) -> int { return __builtin_amdgcn_readfirstlane(x); };
     auto rfl64 = [&](unsigned long long x) __attribute__((always_inline)) -> unsigned long long {
         return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x);
-    };
-    auto gather_at = [&](int t) __attribute__((always_inline)) -> int {       // (always executed: a clamped LDS read; used only by gathered pieces)
-        return lds_idx[(gselP == 2 ? a.B : 0) + min(t * BK + brow, a.B - 1)];
     };
     auto loader_switch = [&](int v) {                // make the state valid for the issue of virtual step v
         const int vv = min(v, V - 1);                            // (virtual steps beyond the sequence re-load the last tile; never consumed)
@@ -172,14 +174,17 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
         const long long r0 = (long long)t * BK;
         const bool clamp = !gsel && r0 + BK > rv;                // some row of THIS step lies beyond the rows that exist: per-lane row clamp, one step
         const int col = min(n0 + 4 * bq, ncl), r = (int)r0 + brow;
-        lq = q; tN = t; gselP = gsel; vsP = soft ? 1.f : 0.f; ldx4 = (unsigned)ldx * 4u;
-        aB = (const char*)(uintptr_t)a_ptr + r0 * a.H * 4;
-        if (gsel)       { xB = (const char*)(uintptr_t)x_ptr;                 offX = (unsigned)(col * 4); }
-        else if (clamp) { xB = (const char*)(uintptr_t)x_ptr;                 offX = (unsigned)(((long long)min(r, rv - 1) * ldx + col) * 4); }
-        else            { xB = (const char*)(uintptr_t)x_ptr + r0 * ldx * 4;  offX = (unsigned)((brow * ldx + col) * 4); }
-        if (!soft)      { lB = (const char*)(uintptr_t)l_ptr;                 offL = 0u; }
-        else if (clamp) { lB = (const char*)(uintptr_t)l_ptr;                 offL = (unsigned)(min(r, rv - 1) * 4); }
-        else            { lB = (const char*)(uintptr_t)l_ptr + r0 * 4;        offL = (unsigned)(brow * 4); }
+        lq = q; vsP = soft ? 1.f : 0.f; ldx4 = gsel ? (unsigned)ldx * 4u : 0u;             // (ldx4 = 0: the gathered-row term of the X offset vanishes)
+        // (operand extents are below 4 GiB: host-checked)
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)a_ptr, 0, 0xFFFFFFF0u, 0x00020000);
+        rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)x_ptr, 0, 0xFFFFFFF0u, 0x00020000);
+        aO = (unsigned)(r0 * a.H * 4);
+        if (gsel)       { xO = 0u;                         offX = (unsigned)(col * 4); }
+        else if (clamp) { xO = 0u;                         offX = (unsigned)(((long long)min(r, rv - 1) * ldx + col) * 4); }
+        else            { xO = (unsigned)(r0 * ldx * 4);   offX = (unsigned)((brow * ldx + col) * 4); }
+        if (!soft)      { lB = (const char*)(uintptr_t)l_ptr;            offL = 0u; }
+        else if (clamp) { lB = (const char*)(uintptr_t)l_ptr;            offL = (unsigned)(min(r, rv - 1) * 4); }
+        else            { lB = (const char*)(uintptr_t)l_ptr + r0 * 4;   offL = (unsigned)(brow * 4); }
         if (v >= V - 1) {                                        // the last tile of the sequence, and every issue after it: stay
             aS = 0; xS = 0; lS = 0; l_vend = 0x7fffffff;
         } else {
@@ -189,18 +194,21 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
             if (!gsel && (long long)(t0 + (vend - vbeg)) * BK > (long long)rv) ve = min(ve, vbeg + (rv / BK - t0));      // (step rv / BK is the first with a row beyond rv)
             l_vend = clamp ? v + 1 : max(ve, v + 1);
         }
-        rgn = gather_at(t);
+        // (the "stay" state re-reads the same table entry: an index that kept advancing past the 32 spare entries named rows that do not exist)
+        gi = gsel ? (gsel == 2 ? IB : 0) + min((int)r0 + brow, a.B - 1) : 0; gS = (gsel && v < V - 1) ? BK : 0;
+        rgn = lds_idx[gi]; gi += gS;
     };
     auto issue_fast = [&](auto set_c) __attribute__((always_inline)) {
         constexpr int S = decltype(set_c)::value;
+        typedef unsigned int bu32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int i = 0; i < NA; ++i) va[S][i] = *(tn_gf4ptr)(aB + offA[i]);
-        const unsigned xo = gselP ? __umul24((unsigned)rgn, ldx4) + offX : offX;
-        vb[S] = *(tn_gf4ptr)(xB + xo);
+        for (int i = 0; i < NA; ++i) va[S][i] = __builtin_bit_cast(f32x4, (bu32x4)__builtin_amdgcn_raw_buffer_load_b128(rsA, offA[i], aO, 0));
+        const unsigned xo = __umul24((unsigned)rgn, ldx4) + offX;
+        vb[S] = __builtin_bit_cast(f32x4, (bu32x4)__builtin_amdgcn_raw_buffer_load_b128(rsX, xo, xO, 0));
         vl[S] = *(tn_gfptr)(lB + offL);
         vs[S] = vsP;
-        aB += aS; xB += xS; lB += lS; ++tN;
-        rgn = gather_at(tN);
+        aO += aS; xO += xS; lB += lS;
+        rgn = lds_idx[gi]; gi += gS;                             // (always executed; used only by gathered pieces, whose tables have 32 spare entries)
     };
     auto issue = [&](auto set_c, int v) __attribute__((always_inline)) {        // (prologue)
         if (v >= l_vend) loader_switch(v);
@@ -534,6 +542,9 @@ bool dw_tn8_shapes_ok(const ncx_dims& d) {
     // tables fit in LDS; enough k-steps per chunk to be worth a pipeline (below that the generic engine's plans are as good)
     if (d.H % TN8_BM != 0 || d.B % TN8_BK != 0 || M % TN8_BK != 0 || d.B > 4096 || d.B < 128) return false;
     if (d.dv % 4 || d.dq % 4 || d.dz % 4 || d.da % 4 || d.A % 4) return false;
+    // the loader's buffer loads take 32-bit byte offsets: every operand (the feature table, the logits, dpre) below 4 GiB
+    const long long lim = (1ll << 32) - 65536;
+    if ((long long)d.n_img * d.dv * 4 >= lim || M * (long long)(d.A > d.da ? d.A : d.da) * 4 >= lim || M * (long long)d.H * 4 >= lim || (long long)d.A * d.da * 4 >= lim) return false;
     return true;
 }
 
@@ -622,9 +633,9 @@ int dw_tn8_products(const ncx_dims& d, const Tn8Prob* probs, int np, int n_al, b
         NCX_HIP_TRY(hipGetLastError());
         return NCX_OK;
     }
-    const int lds = 2 * TN8_BK * (TN8_PA + TN8_PB) * 4 + TN8_MAX_SEG * (int)sizeof(Tn8Seg) + 2 * d.B * 4;
+    const int lds = 2 * TN8_BK * (TN8_PA + TN8_PB) * 4 + TN8_MAX_SEG * (int)sizeof(Tn8Seg) + 2 * (d.B + 32) * 4;
     static DevMask attr{0};
-    NCX_HIP_TRY(set_max_lds_once(attr, (const void*)k_dw_tn8, 2 * TN8_BK * (TN8_PA + TN8_PB) * 4 + TN8_MAX_SEG * (int)sizeof(Tn8Seg) + 2 * 4096 * 4));
+    NCX_HIP_TRY(set_max_lds_once(attr, (const void*)k_dw_tn8, 2 * TN8_BK * (TN8_PA + TN8_PB) * 4 + TN8_MAX_SEG * (int)sizeof(Tn8Seg) + 2 * (4096 + 32) * 4));
     hipLaunchKernelGGL(k_dw_tn8, dim3(pl.grid), dim3(TN8_T), lds, s, a);
     NCX_HIP_TRY(hipGetLastError());
     return NCX_OK;
