@@ -341,14 +341,15 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8_x6(const Tn8Args a) {
     constexpr int NA = 4;
     extern __shared__ __attribute__((aligned(1024))) unsigned char tn6_smem[];
     Tn8Seg* const segs = (Tn8Seg*)(tn6_smem + 2 * BUF);          // [TN8_MAX_SEG]
-    int* const lds_idx = (int*)(segs + TN8_MAX_SEG);            // [2][B]
+    int* const lds_idx = (int*)(segs + TN8_MAX_SEG);            // [2][B + 32]
+    const int IB = a.B + 32;
     __shared__ int s_nseg, s_vtot;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
     const int wm0 = 64 * (wave >> 1), wn0 = 32 * (wave & 1);
     const int w = blockIdx.x;
     if (tid == 0) tn8_pieces(a, w, segs, &s_nseg, &s_vtot);
     if (a.do_rest) {
-        for (int i = tid; i < a.B; i += T) { lds_idx[i] = a.idx_ob ? a.idx_ob[i] : 0; lds_idx[a.B + i] = a.aid ? a.aid[i] : 0; }
+        for (int i = tid; i < IB; i += T) { const int ii = min(i, a.B - 1); lds_idx[i] = a.idx_ob ? a.idx_ob[ii] : 0; lds_idx[IB + i] = a.aid ? a.aid[ii] : 0; }
     }
     __syncthreads();
     const int nseg = s_nseg, V = s_vtot;
@@ -365,29 +366,80 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8_x6(const Tn8Args a) {
     const int brow = tid >> 4, bq = tid & 15;
     f32x4 va[2][NA], vb[2];
     float vl[2], vs[2];
-    int qi = 0;
-    Tn8Seg dn = segs[0];
-    auto gather_row = [&](const Tn8Seg& sg, int v) __attribute__((always_inline)) -> int {
-        const int r = (sg.t0 + (min(v, V - 1) - sg.vbeg)) * BK + brow;
-        return lds_idx[(sg.gsel == 2 ? a.B : 0) + (sg.gsel ? min(r, a.B - 1) : 0)];
-    };
-    int rgn = gather_row(dn, 0);
-    auto issue = [&](auto set_c, int v) __attribute__((always_inline)) {
-        constexpr int S = decltype(set_c)::value;
-        const int vv = min(v, V - 1);
-        const int t = dn.t0 + (vv - dn.vbeg);
-        const long long r0 = (long long)t * BK;
-        const tn_gfptr ap = (tn_gfptr)(uintptr_t)dn.a_ptr + (r0 + arow) * a.H + 4 * aq;
+    // The loader of k_dw_tn8 (this kernel is bound by its vector instructions and its LDS / load-return traffic: the loader that recomputed every address from
+    // the piece record cost ~25 vector instructions per k-step).  So an issue is `uniform base + 32-bit lane offset`, the bases advanced by scalar arithmetic (issue_fast, the
+    // only loader code inside a step); whenever the NEXT issue enters a new piece, needs the row clamp (the last rows of a padded problem) or runs past the
+    // sequence, loader_switch() re-derives the state from the piece record BETWEEN two steps (a uniform branch in the loop, not in the step).  Same addresses,
+    // same values as before: results are bit-identical.
+    int lq = 0, l_vend = 0;                                     // uniform: piece of the last switch; first virtual step the advanced state is NOT valid for
+    // (buffer loads: descriptor = the piece's operand base, voffset = the lane's constant offset, soffset = the step's uniform offset: no vector instruction per load)
+    // (the one-float lse load keeps its pointer: a third descriptor did not stay in scalar registers and hipcc wrapped that load in a waterfall loop)
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)nullptr, 0, 0, 0x00020000), rsX = rsA;
+    const char* lB = nullptr;
+    unsigned aO = 0, xO = 0;                                    // uniform byte offsets of the next issue
+    unsigned aS = 0, xS = 0, lS = 0, ldx4 = 0;                  // uniform strides per k-step (bytes); row pitch of the gathered operand (bytes)
+    int gi = 0, gS = 0;                                         // per-lane index into the gather tables for the issue after next; its uniform stride (0: no gather)
+    float vsP = 0.f;
+    unsigned offA[NA], offX = 0, offL = 0;                      // per-lane byte offsets
 #pragma unroll
-        for (int i = 0; i < NA; ++i) va[S][i] = *(tn_gf4ptr)(ap + (long long)(8 * i) * a.H);
-        const int r = (int)r0 + brow;
-        const long long xr = dn.gsel ? (long long)rgn : (long long)min(r, dn.rv - 1);
-        vb[S] = *(tn_gf4ptr)((tn_gfptr)(uintptr_t)dn.x_ptr + xr * dn.ldx + min(dn.n0 + 4 * bq, dn.ncl));
-        vl[S] = ((tn_gfptr)(uintptr_t)dn.l_ptr)[dn.soft ? min(r, dn.rv - 1) : 0];
-        vs[S] = dn.soft ? 1.f : 0.f;
-        qi += (v + 1 >= dn.vend && qi + 1 < nseg) ? 1 : 0;
-        dn = segs[qi];
-        rgn = gather_row(dn, v + 1);
+    for (int i = 0; i < NA; ++i) offA[i] = (unsigned)(((arow + 8 * i) * a.H + 4 * aq) * 4);
+    int rgn = 0;                                                // gathered row of the next issue
+    auto rfl = [&](int x) __attribute__((always_inline)) -> int { return __builtin_amdgcn_readfirstlane(x); };
+    auto rfl64 = [&](unsigned long long x) __attribute__((always_inline)) -> unsigned long long {
+        return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x);
+    };
+    auto loader_switch = [&](int v) {                // make the state valid for the issue of virtual step v
+        const int vv = min(v, V - 1);                            // (virtual steps beyond the sequence re-load the last tile; never consumed)
+        int q = lq;
+        while (q + 1 < nseg && vv >= segs[q].vend) ++q;
+        q = rfl(q);
+        const Tn8Seg sg = segs[q];
+        const unsigned long long a_ptr = rfl64(sg.a_ptr), x_ptr = rfl64(sg.x_ptr), l_ptr = rfl64(sg.l_ptr);
+        const int ldx = rfl(sg.ldx), soft = rfl(sg.soft), gsel = rfl(sg.gsel), n0 = rfl(sg.n0), ncl = rfl(sg.ncl), t0 = rfl(sg.t0), vbeg = rfl(sg.vbeg),
+                  vend = rfl(sg.vend), rv = rfl(sg.rv);
+        const int t = t0 + (vv - vbeg);
+        const long long r0 = (long long)t * BK;
+        const bool clamp = !gsel && r0 + BK > rv;                // some row of THIS step lies beyond the rows that exist: per-lane row clamp, one step
+        const int col = min(n0 + 4 * bq, ncl), r = (int)r0 + brow;
+        lq = q; vsP = soft ? 1.f : 0.f; ldx4 = gsel ? (unsigned)ldx * 4u : 0u;             // (ldx4 = 0: the gathered-row term of the X offset vanishes)
+        // (operand extents are below 4 GiB: host-checked)
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)a_ptr, 0, 0xFFFFFFF0u, 0x00020000);
+        rsX = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)x_ptr, 0, 0xFFFFFFF0u, 0x00020000);
+        aO = (unsigned)(r0 * a.H * 4);
+        if (gsel)       { xO = 0u;                         offX = (unsigned)(col * 4); }
+        else if (clamp) { xO = 0u;                         offX = (unsigned)(((long long)min(r, rv - 1) * ldx + col) * 4); }
+        else            { xO = (unsigned)(r0 * ldx * 4);   offX = (unsigned)((brow * ldx + col) * 4); }
+        if (!soft)      { lB = (const char*)(uintptr_t)l_ptr;            offL = 0u; }
+        else if (clamp) { lB = (const char*)(uintptr_t)l_ptr;            offL = (unsigned)(min(r, rv - 1) * 4); }
+        else            { lB = (const char*)(uintptr_t)l_ptr + r0 * 4;   offL = (unsigned)(brow * 4); }
+        if (v >= V - 1) {                                        // the last tile of the sequence, and every issue after it: stay
+            aS = 0; xS = 0; lS = 0; l_vend = 0x7fffffff;
+        } else {
+            aS = (unsigned)(BK * a.H * 4); xS = (gsel || clamp) ? 0u : (unsigned)(BK * ldx * 4); lS = (soft && !clamp) ? (unsigned)(BK * 4) : 0u;
+            // valid until the piece ends, the first step that needs the clamp, or the last step of the sequence (which switches to "stay")
+            int ve = min(vend, V - 1);
+            if (!gsel && (long long)(t0 + (vend - vbeg)) * BK > (long long)rv) ve = min(ve, vbeg + (rv / BK - t0));      // (step rv / BK is the first with a row beyond rv)
+            l_vend = clamp ? v + 1 : max(ve, v + 1);
+        }
+        // (the "stay" state re-reads the same table entry: an index that kept advancing past the 32 spare entries named rows that do not exist)
+        gi = gsel ? (gsel == 2 ? IB : 0) + min((int)r0 + brow, a.B - 1) : 0; gS = (gsel && v < V - 1) ? BK : 0;
+        rgn = lds_idx[gi]; gi += gS;
+    };
+    auto issue_fast = [&](auto set_c) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_c)::value;
+        typedef unsigned int bu32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < NA; ++i) va[S][i] = __builtin_bit_cast(f32x4, (bu32x4)__builtin_amdgcn_raw_buffer_load_b128(rsA, offA[i], aO, 0));
+        const unsigned xo = __umul24((unsigned)rgn, ldx4) + offX;
+        vb[S] = __builtin_bit_cast(f32x4, (bu32x4)__builtin_amdgcn_raw_buffer_load_b128(rsX, xo, xO, 0));
+        vl[S] = *(tn_gfptr)(lB + offL);
+        vs[S] = vsP;
+        aO += aS; xO += xS; lB += lS;
+        rgn = lds_idx[gi]; gi += gS;                             // (always executed; used only by gathered pieces, whose tables have 32 spare entries)
+    };
+    auto issue = [&](auto set_c, int v) __attribute__((always_inline)) {        // (prologue)
+        if (v >= l_vend) loader_switch(v);
+        issue_fast(set_c);
     };
     // x -> three bf16 planes (four values: one 8-byte store per plane)
     auto split_store = [&](f32x4 v, unsigned char* base) __attribute__((always_inline)) {
@@ -426,11 +478,11 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8_x6(const Tn8Args a) {
     };
     typedef __attribute__((address_space(3))) tn_s16x4* lds_s16x4;
     const int tq = li >> 2, tp = li & 3;
-    const int offA = (4 * lk + tq) * PA + (wm0 + 4 * tp) * 2, offB = A_PL + (4 * lk + tq) * PB + (wn0 + 4 * tp) * 2;
+    const int fragA = (4 * lk + tq) * PA + (wm0 + 4 * tp) * 2, fragB = A_PL + (4 * lk + tq) * PB + (wn0 + 4 * tp) * 2;
     auto read_a = [&](int buf, int i, tn_bf16x8 (&af)[3]) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            const unsigned char* ta = tn6_smem + buf * BUF + p * PL + offA + i * 32;
+            const unsigned char* ta = tn6_smem + buf * BUF + p * PL + fragA + i * 32;
             const tn_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ta));
             const tn_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ta + 16 * PA));
             af[p] = __builtin_bit_cast(tn_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -441,7 +493,7 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8_x6(const Tn8Args a) {
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const unsigned char* tb = tn6_smem + buf * BUF + p * PL + offB + j * 32;
+                const unsigned char* tb = tn6_smem + buf * BUF + p * PL + fragB + j * 32;
                 const tn_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tb));
                 const tn_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tb + 16 * PB));
                 bf[p][j] = __builtin_bit_cast(tn_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -511,7 +563,7 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8_x6(const Tn8Args a) {
         __builtin_amdgcn_sched_barrier(0);
         read_a(PAR, 1, afB); stash(SS{}, PAR ^ 1, 0, 2); mfma12(afA, bfr[PAR], acc[0]); pin();
         read_a(PAR, 2, afA); stash(SS{}, PAR ^ 1, 2, NA + 1); mfma12(afB, bfr[PAR], acc[1]); pin();
-        read_a(PAR, 3, afB); issue(SS{}, v + 3); mfma12(afA, bfr[PAR], acc[2]); pin();
+        read_a(PAR, 3, afB); issue_fast(SS{}); mfma12(afA, bfr[PAR], acc[2]); pin();       // (virtual step v + 3: the loop made the state valid for it)
         __syncthreads();
         if (v + 1 == vend_c) {                           // the piece ends here (uniform): block row 3, partial tile out, next piece
             mfma12(afB, bfr[PAR], acc[3]);
@@ -523,8 +575,13 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8_x6(const Tn8Args a) {
         }
     };
     int v = 0;
-    for (; v + 1 < V; v += 2) { step(S0{}, v); step(S1{}, v + 1); }
-    if (v < V) step(S0{}, v);
+    for (; v + 1 < V; v += 2) {
+        if (v + 3 >= l_vend) loader_switch(v + 3);
+        step(S0{}, v);
+        if (v + 4 >= l_vend) loader_switch(v + 4);
+        step(S1{}, v + 1);
+    }
+    if (v < V) { if (v + 3 >= l_vend) loader_switch(v + 3); step(S0{}, v); }
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------------------------------
@@ -626,9 +683,9 @@ int dw_tn8_products(const ncx_dims& d, const Tn8Prob* probs, int np, int n_al, b
     if (!a.do_al && !a.do_rest) { red->n_tiles_total = 0; return NCX_OK; }
     a.idx_ob = idx_ob; a.aid = aid;
     if (dw_tn8_x6(d)) {
-        const int lds = 2 * TN6_BUF + TN8_MAX_SEG * (int)sizeof(Tn8Seg) + 2 * d.B * 4;
+        const int lds = 2 * TN6_BUF + TN8_MAX_SEG * (int)sizeof(Tn8Seg) + 2 * (d.B + 32) * 4;
         static DevMask attr6{0};
-        NCX_HIP_TRY(set_max_lds_once(attr6, (const void*)k_dw_tn8_x6, 2 * TN6_BUF + TN8_MAX_SEG * (int)sizeof(Tn8Seg) + 2 * TN6_MAX_B * 4));
+        NCX_HIP_TRY(set_max_lds_once(attr6, (const void*)k_dw_tn8_x6, 2 * TN6_BUF + TN8_MAX_SEG * (int)sizeof(Tn8Seg) + 2 * (TN6_MAX_B + 32) * 4));
         hipLaunchKernelGGL(k_dw_tn8_x6, dim3(pl.grid), dim3(TN8_T), lds, s, a);
         NCX_HIP_TRY(hipGetLastError());
         return NCX_OK;
