@@ -258,7 +258,7 @@ constexpr int KM8_LDS = 2 * (24 * KM8_PA + 32 * KM8_PB) * 4;
 __global__ __launch_bounds__(512, 1) void k_dw_km8(const float* __restrict__ dpre, int H, const float* __restrict__ feats, int dv,
                                                    const int* __restrict__ idx_k, const int* __restrict__ idx_o, int B, int Kc,
                                                    int chunk, int tiles_m, int S, float* __restrict__ slab) {
-    constexpr int T = 512, BM = 256, BN = 64, K = 24, PA = KM8_PA, PB = KM8_PB, NA = 3;
+    constexpr int BM = 256, BN = 64, K = 24, PA = KM8_PA, PB = KM8_PB, NA = 3;
     constexpr int A_EL = K * PA, B_EL = 32 * PB;
     extern __shared__ __attribute__((aligned(16))) float km8_smem[];
     float* const lds_a = km8_smem;                     // [2][24][PA]
@@ -283,8 +283,6 @@ __global__ __launch_bounds__(512, 1) void k_dw_km8(const float* __restrict__ dpr
         }
     const int arow = tid >> 6, aq = tid & 63;
     const int brow = tid >> 4, bq = tid & 15;
-    typedef const __attribute__((address_space(1))) float* gfp;
-    typedef const __attribute__((address_space(1))) f32x4u* gf4p;
     typedef const __attribute__((address_space(1))) int* gip;
     f32x4 va[2][NA], vb[2];
     auto load_idx = [&](int b) __attribute__((always_inline)) -> int {
@@ -465,8 +463,6 @@ __global__ __launch_bounds__(512, 1) void k_dw_km_x6(const float* __restrict__ d
 
     const int arow = tid >> 6, aq = tid & 63;
     const int brow = tid >> 4, bq = tid & 15;                      // rows 0 .. 23: v_k of the step's rows; rows 24 .. 31: the triplet's v_o (same quad, same value)
-    typedef const __attribute__((address_space(1))) float* gfp;
-    typedef const __attribute__((address_space(1))) f32x4u* gf4p;
     typedef const __attribute__((address_space(1))) int* gip;
     f32x4 va[2][NA], vb[2];
     auto load_idx = [&](int b) __attribute__((always_inline)) -> int {
@@ -474,17 +470,23 @@ __global__ __launch_bounds__(512, 1) void k_dw_km_x6(const float* __restrict__ d
         return brow < K ? ((gip)idx_k)[r0 + brow] : ((gip)idx_o)[r0];
     };
     int ixn = load_idx(b0);                                        // gather row of the NEXT issue (requested one issue ahead)
+    // (buffer loads: descriptor + 32-bit lane offset + scalar step offset, as k_dw_km8)
+    typedef unsigned int bu32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dpre), 0, 0xFFFFFFF0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(feats), 0, 0xFFFFFFF0u, 0x00020000);
+    unsigned offA[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) offA[i] = (unsigned)(((arow + 8 * i) * H + m0 + 4 * aq) * 4);
+    const unsigned offX = (unsigned)((n0 + 4 * bq) * 4), dv4 = (unsigned)dv * 4u;
     auto issue = [&](auto set_c, int b) __attribute__((always_inline)) {
         constexpr int SS_ = decltype(set_c)::value;
         const long long r0 = (long long)min(b, b1 - 1) * K;
-        const gfp ap = (gfp)dpre + (r0 + arow) * H + m0 + 4 * aq;
-        // (the index request goes out FIRST: it is the load the next issue needs soonest, and vmcnt counts in order -- as the youngest load of the
-        // issue it made the next issue wait for every quad of this one)
-        const int ix = ixn;
+        const unsigned ao = (unsigned)(r0 * H * 4);                      // uniform
+        const int ix = ixn;                                              // (the index request first: vmcnt counts in order)
         ixn = load_idx(b + 1);
 #pragma unroll
-        for (int i = 0; i < NA; ++i) va[SS_][i] = *(gf4p)(ap + (long long)(8 * i) * H);
-        vb[SS_] = *(gf4p)((gfp)feats + (long long)ix * dv + n0 + 4 * bq);
+        for (int i = 0; i < NA; ++i) va[SS_][i] = __builtin_bit_cast(f32x4, (bu32x4)__builtin_amdgcn_raw_buffer_load_b128(rsD, offA[i], ao, 0));
+        vb[SS_] = __builtin_bit_cast(f32x4, (bu32x4)__builtin_amdgcn_raw_buffer_load_b128(rsF, __umul24((unsigned)ix, dv4) + offX, 0, 0));
     };
     auto split_store = [&](f32x4 v, unsigned char* base) __attribute__((always_inline)) {
         unsigned p1[4], p2[4], p3[4];
@@ -520,11 +522,11 @@ __global__ __launch_bounds__(512, 1) void k_dw_km_x6(const float* __restrict__ d
     };
     typedef __attribute__((address_space(3))) km_s16x4* lds_s16x4;
     const int tq = li >> 2, tp = li & 3;
-    const int offA = (4 * lk + tq) * PA + (wm0 + 4 * tp) * 2, offB = A_PL + (4 * lk + tq) * PB + (wn0 + 4 * tp) * 2;
+    const int fragA = (4 * lk + tq) * PA + (wm0 + 4 * tp) * 2, fragB = A_PL + (4 * lk + tq) * PB + (wn0 + 4 * tp) * 2;
     auto read_a = [&](int buf, int i, km_bf16x8 (&af)[3]) __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            const unsigned char* ta = km6_smem + buf * BUF + p * PL + offA + i * 32;
+            const unsigned char* ta = km6_smem + buf * BUF + p * PL + fragA + i * 32;
             const km_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ta));
             const km_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(ta + 16 * PA));
             af[p] = __builtin_bit_cast(km_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(512, 1) void k_dw_km_x6(const float* __restrict__ d
         for (int p = 0; p < 3; ++p)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const unsigned char* tb = km6_smem + buf * BUF + p * PL + offB + j * 32;
+                const unsigned char* tb = km6_smem + buf * BUF + p * PL + fragB + j * 32;
                 const km_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tb));
                 const km_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(tb + 16 * PB));
                 bf[p][j] = __builtin_bit_cast(km_bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -712,7 +714,7 @@ int dw_km(const ncx_dims& d, const float* dpre, const float* feats, const int* i
         NCX_HIP_TRY(hipGetLastError());
         return finish ? dw_km_finish(d, slab, g_vother, g_vmult, din, nullptr, 0, s) : NCX_OK;
     }
-    if (x6 && d.H % 256 == 0 && d.dv % 64 == 0) {      // (K % 24 == 0: dw_km_supported)
+    if (x6 && d.H % 256 == 0 && d.dv % 64 == 0 && fits32) {      // (K % 24 == 0: dw_km_supported)
         static DevMask attr6{0};
         NCX_HIP_TRY(set_max_lds_once(attr6, (const void*)k_dw_km_x6, KM6_LDS));
         hipLaunchKernelGGL(k_dw_km_x6, dim3((d.H / 256) * (d.dv / 64) * S), dim3(512), KM6_LDS, s, dpre, d.H, feats, d.dv, idx_k, idx_o, d.B, d.K, chunk, d.H / 256, S, slab);

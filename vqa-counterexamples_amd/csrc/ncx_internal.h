@@ -144,10 +144,16 @@ WsLayout ws_layout(const ncx_dims& d);
 __host__ __device__ static inline int pad_to(int x, int m) { return (x + m - 1) / m * m; }
 // The fused forward kernel (ncx_main.h) takes operands whose widths are multiples of 4 (16-byte windows, no straddling);
 // other shapes (only the ragged test shapes: every real width is a multiple of 8) run on the generic engine.
-static inline bool main_fwd_dims_ok(const ncx_dims& d) {
-    return d.dv % 4 == 0 && d.dz % 4 == 0 && ((d.flags & NCX_F_A_EMB) ? d.A : d.da) % 4 == 0 && !(d.flags & NCX_F_BF16);
+// ... and whose extents are below 4 GiB (its loads are buffer loads with 32-bit byte offsets: the feature table, the candidate logits, the activations).
+static inline bool main_fwd_extents_ok(const ncx_dims& d) {
+    const long long lim = (1ll << 32) - 65536, M = (long long)d.B * d.K, wa = d.A > d.da ? d.A : d.da;
+    return (long long)d.n_img * d.dv * 4 < lim && M * wa * 4 < lim && M * (long long)d.H * 4 < lim && M * (long long)d.dz * 4 < lim && (long long)d.A * wa * 4 < lim &&
+           (long long)d.H * (2ll * d.dv + d.dq + 2ll * d.dz + 2ll * d.da + d.K + 2) * 4 < lim;
 }
-static inline bool hidden_fwd_dims_ok(const ncx_dims& d) { return d.H % 4 == 0; }
+static inline bool main_fwd_dims_ok(const ncx_dims& d) {
+    return d.dv % 4 == 0 && d.dz % 4 == 0 && ((d.flags & NCX_F_A_EMB) ? d.A : d.da) % 4 == 0 && !(d.flags & NCX_F_BF16) && main_fwd_extents_ok(d);
+}
+static inline bool hidden_fwd_dims_ok(const ncx_dims& d) { return d.H % 4 == 0 && main_fwd_extents_ok(d); }
 // private flag bit (never set by callers: check_dims rejects it): the pairwise distance is computed inside the fused forward
 // kernel, k_prep leaves the feature rows alone
 constexpr uint32_t NCX_F_PRIV_DIST_IN_MAIN = 1u << 30;

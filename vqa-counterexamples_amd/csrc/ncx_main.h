@@ -200,7 +200,12 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
 
     // Global-load register sets and operand pointers of the segment being loaded (shared by all segments).
     f32x4 va[DEPTH][NA], vm[DEPTH][NA], vb[DEPTH][NB];
-    gfptr pa[NA]; gfptr pm[NA]; gfptr pb[NB]; float lse[NA];
+    // Operand loads are buffer loads: descriptor (the segment's base) + a 32-bit per-lane byte offset; the weight side adds the k-step's offset in a scalar
+    // register (no vector instruction per load), the operand side its slid window (vector instructions are not hidden under fp32 MFMAs: DESIGN S5d).
+    // Every caller keeps operand extents below 4 GiB (main_fwd_extents_ok).
+    typedef unsigned int bu32x4 __attribute__((ext_vector_type(4)));
+    __amdgpu_buffer_rsrc_t rsPA = __builtin_amdgcn_make_buffer_rsrc((void*)nullptr, 0, 0, 0x00020000), rsPB = rsPA;
+    unsigned roA[NA], roM[NA], roB[NB]; float lse[NA];
     float dacc[NA];                                      // DIST: sum (v_o - v_k + 1e-6)^2 over this thread's column quads, per A row
     // (one-triplet-per-wave fold forms: the finished distances of the tile's rows wait here, behind the LDS of the segments that follow and of the layout conversion)
     constexpr int FOLD_DIST_OFF = 2 * (BML + BN) * P > 32 * (MT / 64) * 68 ? 2 * (BML + BN) * P : 32 * (MT / 64) * 68;
@@ -212,29 +217,31 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
         for (int i = 0; i < NA; ++i) {
             const int r = min(m0 + min(trow + RP * i, BM - 1), M - 1);          // (rows beyond the tile / the matrix: clamped, never stored)
             constexpr bool GAT = KIND == MK_GATHER || KIND == MK_GATHER_MUL;
-            const long long row = GAT ? (long long)((giptr)g.idx)[r] : (long long)r;
-            pa[i] = (gfptr)g.a + row * g.lda;
-            pm[i] = KIND == MK_GATHER_MUL ? (gfptr)g.a + (long long)((giptr)g.idx2)[r] * g.lda : pa[i];
+            const unsigned row = GAT ? (unsigned)((giptr)g.idx)[r] : (unsigned)r;
+            roA[i] = row * (unsigned)(g.lda * 4);
+            roM[i] = KIND == MK_GATHER_MUL ? (unsigned)((giptr)g.idx2)[r] * (unsigned)(g.lda * 4) : roA[i];
             lse[i] = KIND == MK_SOFTMAX ? ((gfptr)g.lse)[r] : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) pb[i] = (gfptr)g.b + (long long)min(n0 + trow + RP * i, N - 1) * g.ldb;
+        for (int i = 0; i < NB; ++i) roB[i] = (unsigned)min(n0 + trow + RP * i, N - 1) * (unsigned)(g.ldb * 4) + 16u * quad;
+        rsPA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.a), 0, 0xFFFFFFF0u, 0x00020000);
+        rsPB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.b), 0, 0xFFFFFFF0u, 0x00020000);
     };
     // tile t of a segment -> register set S.  Operand side: 16-byte windows slid left to stay inside [0, klen) (klen % 4 == 0:
     // a window is either the true one or entirely beyond the extent, where the zero-padded weights null it); weight side:
     // padded rows, read as they are.  Tiles beyond the segment re-load its last tile and are never stored.
     auto issue = [&](auto set_c, auto mul_c, int klen, int nst, int t) __attribute__((always_inline)) {
         constexpr int S = decltype(set_c)::value;
-        const int ck = min(t, nst - 1) * BK + 4 * quad;
-        const int ca = min(ck, klen - 4);
+        const int tk4 = min(t, nst - 1) * (BK * 4);                       // uniform
+        const unsigned ca4 = (unsigned)min(tk4 + 16 * quad, (klen - 4) * 4);
 #pragma unroll
-        for (int i = 0; i < NA; ++i) va[S][i] = *(gf4ptr)(pa[i] + ca);
+        for (int i = 0; i < NA; ++i) va[S][i] = __builtin_bit_cast(f32x4, (bu32x4)__builtin_amdgcn_raw_buffer_load_b128(rsPA, roA[i] + ca4, 0, 0));
         if (decltype(mul_c)::value) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i) vm[S][i] = *(gf4ptr)(pm[i] + ca);
+            for (int i = 0; i < NA; ++i) vm[S][i] = __builtin_bit_cast(f32x4, (bu32x4)__builtin_amdgcn_raw_buffer_load_b128(rsPA, roM[i] + ca4, 0, 0));
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) vb[S][i] = *(gf4ptr)(pb[i] + ck);
+        for (int i = 0; i < NB; ++i) vb[S][i] = __builtin_bit_cast(f32x4, (bu32x4)__builtin_amdgcn_raw_buffer_load_b128(rsPB, roB[i], tk4, 0));
     };
     typedef IntC<0> S0; typedef IntC<DEPTH - 1> S1;
     typedef std::true_type Tt; typedef std::false_type Ff;
@@ -765,25 +772,27 @@ __global__ __launch_bounds__(CFG::T, CFG::OCC) void k_main_fwd(const MainArgs ar
         // loader items of thread (trow, quad): 0 .. 2 = v_k row trow + 64 i of the tile (triplet rho / 24, candidate rho % 24); ONE float of v_o (triplet
         // (tid >> 5) & 7, column tid & 31: the 8 x 32 floats of the step twice over -- 2 KB of returning loads instead of the 8 KB of a quad per thread);
         // 4 / 5 = row trow of W_k / W_m
-        gfptr pA[3], pB[2];
+        // (buffer loads: descriptor + constant lane offset + scalar step offset, no vector instruction per load -- as in run_vfold4)
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.a), 0, 0xFFFFFFF0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.b), 0, 0xFFFFFFF0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sg.b2), 0, 0xFFFFFFF0u, 0x00020000);
+        typedef unsigned int bu32x4 __attribute__((ext_vector_type(4)));
+        unsigned voA[3], voB;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) pA[i] = (gfptr)sg.a + (long long)((giptr)sg.idx)[min(m0 + trow + 64 * i, M - 1)] * sg.lda;
+        for (int i = 0; i < 3; ++i) voA[i] = (unsigned)((giptr)sg.idx)[min(m0 + trow + 64 * i, M - 1)] * (unsigned)(sg.lda * 4) + 16u * quad;
         const int vo_t = (tid >> 5) & 7, vo_c = tid & 31;
-        const gfptr pV = (gfptr)sg.a + (long long)((giptr)sg.idx2)[min(m0 + 24 * vo_t, M - 1)] * sg.lda + vo_c;
-        {
-            const int n = min(n0 + trow, N - 1);
-            pB[0] = (gfptr)sg.b + (long long)n * sg.ldb; pB[1] = (gfptr)sg.b2 + (long long)n * sg.ldb;
-        }
+        const unsigned voV = (unsigned)((giptr)sg.idx2)[min(m0 + 24 * vo_t, M - 1)] * (unsigned)(sg.lda * 4) + 4u * vo_c;
+        voB = (unsigned)min(n0 + trow, N - 1) * (unsigned)(sg.ldb * 4) + 16u * quad;
         f32x4 va4[2][3], vb4[2][2];
         float vv[2];
         auto vissue = [&](auto set_c, int t) __attribute__((always_inline)) {
             constexpr int SS_ = decltype(set_c)::value;
-            const int c = min(t, nst - 1) * BK + 4 * quad;
+            const int so = min(t, nst - 1) * (BK * 4);
 #pragma unroll
-            for (int i = 0; i < 3; ++i) va4[SS_][i] = *(gf4ptr)(pA[i] + c);
-            vv[SS_] = pV[min(t, nst - 1) * BK];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) vb4[SS_][i] = *(gf4ptr)(pB[i] + c);
+            for (int i = 0; i < 3; ++i) va4[SS_][i] = __builtin_bit_cast(f32x4, (bu32x4)__builtin_amdgcn_raw_buffer_load_b128(rsA, voA[i], so, 0));
+            vv[SS_] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsA, voV, so, 0));
+            vb4[SS_][0] = __builtin_bit_cast(f32x4, (bu32x4)__builtin_amdgcn_raw_buffer_load_b128(rsK, voB, so, 0));
+            vb4[SS_][1] = __builtin_bit_cast(f32x4, (bu32x4)__builtin_amdgcn_raw_buffer_load_b128(rsM, voB, so, 0));
         };
         auto split3 = [&](const float (&x)[4], unsigned (&w1)[2], unsigned (&w2)[2], unsigned (&w3)[2]) __attribute__((always_inline)) {
             unsigned p1[4], p2[4], p3[4];
