@@ -106,6 +106,10 @@ __device__ __forceinline__ void tn8_pieces(const Tn8Args& a, int w, Tn8Seg* segs
     *nseg_out = n; *vtot_out = v;
 }
 
+// SPLIT: only the aligned problem is a softmax operand (what backward_impl launches): the transform of a tile is then known from its position in the
+// workgroup's sequence -- exp2 for the aligned chunk, nothing for the rest -- and the per-element select (a compare + four v_cndmask per k-step, and the unused
+// fma / exp2 of plain pieces) leaves the step.
+template <bool SPLIT>
 __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
     constexpr int T = TN8_T, BM = TN8_BM, BN = TN8_BN, BK = TN8_BK, PA = TN8_PA, PB = TN8_PB;
     constexpr int WM = 4, WN = 2, NA = 4, NMF = 2 * WM * WN;
@@ -214,8 +218,9 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
         if (v >= l_vend) loader_switch(v);
         issue_fast(set_c);
     };
-    auto stash = [&](auto set_c, int buf, int h0, int h1) __attribute__((always_inline)) {
-        constexpr int S = decltype(set_c)::value;
+    // MODE 0: select per element by the set's softmax flag; 1: the tile is a softmax operand; 2: it is a plain one
+    auto stash = [&](auto set_c, auto mode_c, int buf, int h0, int h1) __attribute__((always_inline)) {
+        constexpr int S = decltype(set_c)::value, MODE = decltype(mode_c)::value;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if (i < h0 || i >= h1) continue;
@@ -223,10 +228,12 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
         }
         if (NA >= h0 && NA < h1) {
             f32x4 v = vb[S], e;
+            if (MODE != 2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[j], 1.44269504088896341f, -vl[S]));
+                for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(v[j], 1.44269504088896341f, -vl[S]));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = vs[S] != 0.f ? e[j] : v[j];
+                for (int j = 0; j < 4; ++j) v[j] = MODE == 1 ? e[j] : (vs[S] != 0.f ? e[j] : v[j]);
+            }
             *(f32x4*)(lds_b + buf * BK * PB + brow * PB + 4 * bq) = v;
         }
     };
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
     typedef std::integral_constant<int, 0> S0; typedef std::integral_constant<int, 1> S1;
     issue(S0{}, 0);
     issue(S1{}, 1);
-    stash(S0{}, 0, 0, NA + 1);
+    stash(S0{}, std::integral_constant<int, 0>{}, 0, 0, NA + 1);
     issue(S0{}, 2);
     __syncthreads();
     // the piece being multiplied
@@ -272,8 +279,9 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
                 acc[q][0][rg] = 0.f; acc[q][1][rg] = 0.f;
             }
     };
-    auto step = [&](auto par_c, int v) __attribute__((always_inline)) {
+    auto step = [&](auto par_c, auto mode_c, int v) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_c)::value;
+        typedef decltype(mode_c) MD;
         typedef std::integral_constant<int, PAR ^ 1> SS;
         read_frags(PAR, 0, afA, bfA);
         mfma(afB, bfB);                                  // (v - 1, last sub-step; zeros after a flush): covers the reads above
@@ -285,8 +293,8 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
             auto& afc = (s & 1) ? afB : afA; auto& bfc = (s & 1) ? bfB : bfA;
             auto& afn = (s & 1) ? afA : afB; auto& bfn = (s & 1) ? bfA : bfB;
             read_frags(PAR, s + 1, afn, bfn);
-            if (s == 0) stash(SS{}, PAR ^ 1, 0, 2);
-            if (s == 1) stash(SS{}, PAR ^ 1, 2, NA + 1);
+            if (s == 0) stash(SS{}, MD{}, PAR ^ 1, 0, 2);
+            if (s == 1) stash(SS{}, MD{}, PAR ^ 1, 2, NA + 1);
             if (s == 2) issue_fast(SS{});                     // (virtual step v + 3: the loop made the state valid for it)
             mfma(afc, bfc);
 #pragma unroll
@@ -309,14 +317,27 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8(const Tn8Args a) {
             if (qc < nseg) { vend_c = segs[qc].vend; slot_c = segs[qc].slot; }
         }
     };
-    int v = 0;
-    for (; v + 1 < V; v += 2) {
+    typedef std::integral_constant<int, 0> M0; typedef std::integral_constant<int, 1> M1; typedef std::integral_constant<int, 2> M2;
+    auto pair = [&](auto mode_c, int v) __attribute__((always_inline)) {
         if (v + 3 >= l_vend) loader_switch(v + 3);
-        step(S0{}, v);
+        step(S0{}, mode_c, v);
         if (v + 4 >= l_vend) loader_switch(v + 4);
-        step(S1{}, v + 1);
+        step(S1{}, mode_c, v + 1);
+    };
+    int v = 0;
+    if constexpr (SPLIT) {
+        // step v stores tile v + 1: a softmax operand while v + 1 < nal (the aligned chunk's steps), a plain one from v = nal - 1 on; the loops hand over
+        // at even v (the LDS buffer parity), the 0 or 2 steps in between select per element
+        const int nal = (a.do_al && w < a.al_wgs && segs[0].slot == w) ? segs[0].vend : 0;       // (the aligned chunk's slab slot is the workgroup id: no rest piece has it)
+        const int nA = nal > 1 ? (nal - 1) & ~1 : 0, nB = nal & ~1;
+        for (; v + 1 < V && v < nA; v += 2) pair(M1{}, v);
+        for (; v + 1 < V && v < nB; v += 2) pair(M0{}, v);
+        for (; v + 1 < V; v += 2) pair(M2{}, v);
+        if (v < V) { if (v + 3 >= l_vend) loader_switch(v + 3); step(S0{}, M0{}, v); }
+    } else {
+        for (; v + 1 < V; v += 2) pair(M0{}, v);
+        if (v < V) { if (v + 3 >= l_vend) loader_switch(v + 3); step(S0{}, M0{}, v); }
     }
-    if (v < V) { if (v + 3 >= l_vend) loader_switch(v + 3); step(S0{}, v); }
 }
 
 
@@ -691,9 +712,17 @@ int dw_tn8_products(const ncx_dims& d, const Tn8Prob* probs, int np, int n_al, b
         return NCX_OK;
     }
     const int lds = 2 * TN8_BK * (TN8_PA + TN8_PB) * 4 + TN8_MAX_SEG * (int)sizeof(Tn8Seg) + 2 * (d.B + 32) * 4;
-    static DevMask attr{0};
-    NCX_HIP_TRY(set_max_lds_once(attr, (const void*)k_dw_tn8, 2 * TN8_BK * (TN8_PA + TN8_PB) * 4 + TN8_MAX_SEG * (int)sizeof(Tn8Seg) + 2 * (4096 + 32) * 4));
-    hipLaunchKernelGGL(k_dw_tn8, dim3(pl.grid), dim3(TN8_T), lds, s, a);
+    const int lds_max = 2 * TN8_BK * (TN8_PA + TN8_PB) * 4 + TN8_MAX_SEG * (int)sizeof(Tn8Seg) + 2 * (4096 + 32) * 4;
+    bool split = !hook_env("NCX_TN8_NO_SPLIT");                  // the rest sequence holds plain operands only, the aligned problem (if any) the softmax one
+    for (int i = 0; i < np; ++i) split = split && ((probs[i].lse != nullptr) == (i < n_al));
+    static DevMask attr{0}, attr_s{0};
+    if (split) {
+        NCX_HIP_TRY(set_max_lds_once(attr_s, (const void*)k_dw_tn8<true>, lds_max));
+        hipLaunchKernelGGL(k_dw_tn8<true>, dim3(pl.grid), dim3(TN8_T), lds, s, a);
+    } else {
+        NCX_HIP_TRY(set_max_lds_once(attr, (const void*)k_dw_tn8<false>, lds_max));
+        hipLaunchKernelGGL(k_dw_tn8<false>, dim3(pl.grid), dim3(TN8_T), lds, s, a);
+    }
     NCX_HIP_TRY(hipGetLastError());
     return NCX_OK;
 }
