@@ -357,6 +357,7 @@ typedef unsigned int tn_u32x2 __attribute__((ext_vector_type(2)));
 constexpr int TN6_PA = 544, TN6_PB = 160;                                    // bytes per k-row of one plane (512 + 32, 128 + 32)
 constexpr int TN6_PL = TN8_BK * (TN6_PA + TN6_PB), TN6_BUF = 3 * TN6_PL;    // one plane (A rows | X rows), one buffer
 
+template <bool SPLIT>
 __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8_x6(const Tn8Args a) {
     constexpr int T = TN8_T, BM = TN8_BM, BN = TN8_BN, BK = TN8_BK, PA = TN6_PA, PB = TN6_PB, PL = TN6_PL, BUF = TN6_BUF, A_PL = BK * PA;
     constexpr int NA = 4;
@@ -480,8 +481,8 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8_x6(const Tn8Args a) {
         const tn_u32x2 w3 = {__builtin_amdgcn_perm(p3[1], p3[0], 0x07060302u), __builtin_amdgcn_perm(p3[3], p3[2], 0x07060302u)};
         *(tn_u32x2*)(base) = w1; *(tn_u32x2*)(base + PL) = w2; *(tn_u32x2*)(base + 2 * PL) = w3;
     };
-    auto stash = [&](auto set_c, int buf, int h0, int h1) __attribute__((always_inline)) {
-        constexpr int S = decltype(set_c)::value;
+    auto stash = [&](auto set_c, auto mode_c, int buf, int h0, int h1) __attribute__((always_inline)) {      // MODE: as k_dw_tn8 (0 select, 1 softmax, 2 plain)
+        constexpr int S = decltype(set_c)::value, MODE = decltype(mode_c)::value;
         unsigned char* const base = tn6_smem + buf * BUF;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -490,10 +491,12 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8_x6(const Tn8Args a) {
         }
         if (NA >= h0 && NA < h1) {
             f32x4 v = vb[S], e;
+            if (MODE != 2) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const float xj = v[j]; e[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(xj, 1.44269504088896341f, -vl[S])); }
+                for (int j = 0; j < 4; ++j) { const float xj = v[j]; e[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(xj, 1.44269504088896341f, -vl[S])); }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const float xj = v[j], ej = e[j]; v[j] = vs[S] != 0.f ? ej : xj; }
+                for (int j = 0; j < 4; ++j) { const float xj = v[j], ej = e[j]; v[j] = MODE == 1 ? ej : (vs[S] != 0.f ? ej : xj); }
+            }
             split_store(v, base + A_PL + brow * PB + bq * 8);
         }
     };
@@ -557,7 +560,7 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8_x6(const Tn8Args a) {
     }
     issue(S0{}, 0);
     issue(S1{}, 1);
-    stash(S0{}, 0, 0, NA + 1);
+    stash(S0{}, std::integral_constant<int, 0>{}, 0, 0, NA + 1);
     issue(S0{}, 2);
     __syncthreads();
     int qc = 0, vend_c = segs[0].vend, slot_c = segs[0].slot;
@@ -572,8 +575,9 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8_x6(const Tn8Args a) {
                 for (int j = 0; j < 2; ++j) { slot[row * BN + wn0 + 16 * j + li] = acc[i][j][rg]; acc[i][j][rg] = 0.f; }
             }
     };
-    auto step = [&](auto par_c, int v) __attribute__((always_inline)) {
+    auto step = [&](auto par_c, auto mode_c, int v) __attribute__((always_inline)) {
         constexpr int PAR = decltype(par_c)::value;
+        typedef decltype(mode_c) MD;
         typedef std::integral_constant<int, PAR ^ 1> SS;
         // block row 3 of step v - 1 (zeros at the start and after a flush) over the first reads of this buffer
         read_b(PAR, bfr[PAR]);
@@ -582,8 +586,8 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8_x6(const Tn8Args a) {
 #pragma unroll
         for (int q = 0; q < 12; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); }
         __builtin_amdgcn_sched_barrier(0);
-        read_a(PAR, 1, afB); stash(SS{}, PAR ^ 1, 0, 2); mfma12(afA, bfr[PAR], acc[0]); pin();
-        read_a(PAR, 2, afA); stash(SS{}, PAR ^ 1, 2, NA + 1); mfma12(afB, bfr[PAR], acc[1]); pin();
+        read_a(PAR, 1, afB); stash(SS{}, MD{}, PAR ^ 1, 0, 2); mfma12(afA, bfr[PAR], acc[0]); pin();
+        read_a(PAR, 2, afA); stash(SS{}, MD{}, PAR ^ 1, 2, NA + 1); mfma12(afB, bfr[PAR], acc[1]); pin();
         read_a(PAR, 3, afB); issue_fast(SS{}); mfma12(afA, bfr[PAR], acc[2]); pin();       // (virtual step v + 3: the loop made the state valid for it)
         __syncthreads();
         if (v + 1 == vend_c) {                           // the piece ends here (uniform): block row 3, partial tile out, next piece
@@ -595,15 +599,27 @@ __global__ __launch_bounds__(TN8_T, 1) void k_dw_tn8_x6(const Tn8Args a) {
             if (qc < nseg) { vend_c = segs[qc].vend; slot_c = segs[qc].slot; }
         }
     };
-    int v = 0;
-    for (; v + 1 < V; v += 2) {
+    typedef std::integral_constant<int, 0> M0; typedef std::integral_constant<int, 1> M1; typedef std::integral_constant<int, 2> M2;
+    auto pair = [&](auto mode_c, int v) __attribute__((always_inline)) {
         if (v + 3 >= l_vend) loader_switch(v + 3);
-        step(S0{}, v);
+        step(S0{}, mode_c, v);
         if (v + 4 >= l_vend) loader_switch(v + 4);
-        step(S1{}, v + 1);
+        step(S1{}, mode_c, v + 1);
+    };
+    int v = 0;
+    if constexpr (SPLIT) {
+        const int nal = (a.do_al && w < a.al_wgs && segs[0].slot == w) ? segs[0].vend : 0;
+        const int nA = nal > 1 ? (nal - 1) & ~1 : 0, nB = nal & ~1;
+        for (; v + 1 < V && v < nA; v += 2) pair(M1{}, v);
+        for (; v + 1 < V && v < nB; v += 2) pair(M0{}, v);
+        for (; v + 1 < V; v += 2) pair(M2{}, v);
+        if (v < V) { if (v + 3 >= l_vend) loader_switch(v + 3); step(S0{}, M0{}, v); }
+    } else {
+        for (; v + 1 < V; v += 2) pair(M0{}, v);
+        if (v < V) { if (v + 3 >= l_vend) loader_switch(v + 3); step(S0{}, M0{}, v); }
     }
-    if (v < V) { if (v + 3 >= l_vend) loader_switch(v + 3); step(S0{}, v); }
 }
+
 
 // ---- host ------------------------------------------------------------------------------------------------------------------------------
 static inline int tn8_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
@@ -706,8 +722,16 @@ int dw_tn8_products(const ncx_dims& d, const Tn8Prob* probs, int np, int n_al, b
     if (dw_tn8_x6(d)) {
         const int lds = 2 * TN6_BUF + TN8_MAX_SEG * (int)sizeof(Tn8Seg) + 2 * (d.B + 32) * 4;
         static DevMask attr6{0};
-        NCX_HIP_TRY(set_max_lds_once(attr6, (const void*)k_dw_tn8_x6, 2 * TN6_BUF + TN8_MAX_SEG * (int)sizeof(Tn8Seg) + 2 * (TN6_MAX_B + 32) * 4));
-        hipLaunchKernelGGL(k_dw_tn8_x6, dim3(pl.grid), dim3(TN8_T), lds, s, a);
+        bool split6 = !hook_env("NCX_TN8_NO_SPLIT");
+        for (int i = 0; i < np; ++i) split6 = split6 && ((probs[i].lse != nullptr) == (i < n_al));
+        static DevMask attr6s{0};
+        if (split6) {
+            NCX_HIP_TRY(set_max_lds_once(attr6s, (const void*)k_dw_tn8_x6<true>, 2 * TN6_BUF + TN8_MAX_SEG * (int)sizeof(Tn8Seg) + 2 * (TN6_MAX_B + 32) * 4));
+            hipLaunchKernelGGL(k_dw_tn8_x6<true>, dim3(pl.grid), dim3(TN8_T), lds, s, a);
+        } else {
+            NCX_HIP_TRY(set_max_lds_once(attr6, (const void*)k_dw_tn8_x6<false>, 2 * TN6_BUF + TN8_MAX_SEG * (int)sizeof(Tn8Seg) + 2 * (TN6_MAX_B + 32) * 4));
+            hipLaunchKernelGGL(k_dw_tn8_x6<false>, dim3(pl.grid), dim3(TN8_T), lds, s, a);
+        }
         NCX_HIP_TRY(hipGetLastError());
         return NCX_OK;
     }
