@@ -834,3 +834,21 @@ def test_x6_logits_are_as_close_to_fp64_as_the_fp32_kernels(monkeypatch):
     print("max |logit - fp64|: fp32 kernels %.3e, X6 kernels %.3e" % (err["fp32"], err["x6"]))
     assert err["fp32"] <= 1e-4 and err["x6"] <= 1e-4
     assert err["x6"] <= 1.5 * err["fp32"] + 1e-7
+
+
+def test_a_feature_table_beyond_4_gib_keeps_the_generic_engine():
+    """The forward kernel, the 8-wave fold weight-gradient kernel and the balanced TN launch address their operands with 32-bit byte offsets
+    (buffer loads: DESIGN 4f); a feature table of 4 GiB or more must therefore stay on the generic engine.  Asked of the planner (no such table
+    is allocated): configs[1]'s shape takes the 192-row fold form with the reference's 82 783 images and a plan of the generic engine with 600 000."""
+    from neuralcx import _lib, ops
+    d = orc.Dims()
+    B = 512
+    feats = torch.zeros(8, d.dv, device=dev())
+    idx = torch.zeros(B, d.K + 1, dtype=torch.int32, device=dev())
+    mk = lambda *s: torch.zeros(*s, device=dev())
+    b = ops.Batch(feats, idx, mk(B, d.dq), mk(B, d.dz), mk(B, d.K, d.dz), mk(B, d.K, d.A), torch.zeros(B, dtype=torch.int32, device=dev()))
+    dims = ops.make_dims(b, H=d.H, L=d.L, da=d.da, A=d.A)
+    dims.n_img = 82783
+    assert _lib.plan_query(dims, "MAIN")["tile"].startswith("192x64")
+    dims.n_img = 600000                                    # x 2048 x 4 bytes = 4.9 GB
+    assert "fold" not in _lib.plan_query(dims, "MAIN")["tile"]
